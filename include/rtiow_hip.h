@@ -1,0 +1,170 @@
+/*
+ * rtiow_hip.h -- C ABI of librtiow_hip.so, the MI355X (gfx950) replacement for
+ * the per-pixel Monte-Carlo loop of Druthyn/rtiow.
+ *
+ * What it replaces.  The reference has no FFI or plugin seam: the path is the
+ * inlined iterator expression at src/main.rs:122-139 and everything it calls
+ * (ray_color main.rs:38-57, HittableList::hit shapes/mod.rs:54-70, Sphere::hit
+ * shapes/sphere.rs:15-41, {Lambertian,Metal,Dialectric}::scatter
+ * materials.rs:21-31,48-62,76-105, Camera::get_ray camera.rs:47-54 and
+ * Color::to_rgba vec3.rs:403-421).  Each entry point below names the reference
+ * lines it stands in for; INTEGRATION.md shows the Rust `extern "C"` block and
+ * the edit to main.rs that binds them.
+ *
+ * Rules of the boundary
+ *   - plain C types, plain pointers and sizes; no C++/torch types;
+ *   - every function returns 0 on success or a negative rt_status; it never
+ *     aborts or throws across the ABI (the reference unwrap()s, main.rs:147,177);
+ *     rt_last_error() gives the thread-local message of the last failure;
+ *   - the caller owns every buffer it passes; the library owns the device
+ *     memory tied to an rt_context;
+ *   - a context is used from one host thread at a time; distinct contexts
+ *     (one per GPU) may be used concurrently;
+ *   - there is NO CPU fallback: without a usable gfx950 device rt_create fails.
+ *
+ * Arithmetic.  The path computes in IEEE binary32 under the contract written
+ * in DESIGN.md section 4 (oracle/oracle_b_f32.c is its CPU restatement).  A
+ * pixel's sum over samples is exact: every sample's radiance is truncated to a
+ * 2^-32 grid and summed in an unsigned 64-bit integer, so the result does not
+ * depend on how samples are sharded over lanes, launches, passes or GPUs.
+ */
+#ifndef RTIOW_HIP_H
+#define RTIOW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTIOW_HIP_ABI_VERSION 1
+
+typedef struct rt_context rt_context;
+
+typedef enum {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = -1,
+    RT_ERR_NO_DEVICE = -2,       /* no HIP device / not gfx950 */
+    RT_ERR_HIP = -3,             /* a HIP runtime call failed  */
+    RT_ERR_NO_SCENE = -4,        /* render before rt_upload_scene */
+    RT_ERR_OUT_OF_MEMORY = -5
+} rt_status;
+
+/* Material kinds: the three `impl Scatter` of materials.rs. */
+enum { RT_LAMBERTIAN = 0, RT_METAL = 1, RT_DIALECTRIC = 2 };
+
+/* One sphere, flattened.  The reference keeps Sphere{center,radius,mat}
+ * (shapes/sphere.rs:9-13) and the material structs (materials.rs:9-11,34-37,
+ * 64-66) private behind Box<dyn Hit>/Arc<dyn Scatter>, so the host flattens
+ * each object where it is pushed (main.rs:64,87,93-99).  LIST ORDER IS PART OF
+ * THE INPUT: on equal t the later sphere wins (mod.rs:61-67, sphere.rs:29). */
+typedef struct {
+    float center[3];
+    float radius;
+    int32_t kind;        /* RT_LAMBERTIAN / RT_METAL / RT_DIALECTRIC */
+    float albedo[3];     /* Lambertian, Metal                        */
+    float param;         /* Metal: fuzz; Dialectric: ir              */
+} rt_sphere;             /* 36 bytes */
+
+/* Camera (camera.rs:4-13) minus `w`, which get_ray never reads.  The host
+ * computes it with its Camera::new (camera.rs:17-45) in f64 and rounds. */
+typedef struct {
+    float origin[3];
+    float lower_left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3];
+    float v[3];
+    float lens_radius;
+} rt_camera;             /* 76 bytes */
+
+/* What main.rs:24-28,44 fixes at compile time, plus sharding.
+ *
+ * Rows: j = 0 is the BOTTOM image row, as in main.rs:122-132.  The image is
+ * cut into row tiles of `tile_rows` rows; a call renders the tiles t with
+ * t % shard_count == shard_index, and its output holds those rows only,
+ * ascending j ("compact rows"; rt_shard_rows() gives how many).
+ * shard_count = 1 renders the whole image. */
+typedef struct {
+    int32_t width, height;       /* main.rs:25-26 (>= 2: u,v divide by W-1,H-1)   */
+    int32_t spp;                 /* samples per pixel rendered by this call :27    */
+    int32_t sample_begin;        /* index of the first sample (additive passes)    */
+    int32_t max_depth;           /* :28, 50                                        */
+    float   t_min;               /* :44, 1e-4; must be > 0                         */
+    uint64_t seed;               /* Philox key                                     */
+    int32_t tile_rows;           /* >= 1                                           */
+    int32_t shard_index;         /* 0 <= shard_index < shard_count                 */
+    int32_t shard_count;         /* >= 1                                           */
+    uint32_t flags;              /* RT_FLAG_*                                      */
+} rt_params;
+
+#define RT_FLAG_ACCUMULATE 0x1u  /* rt_render_device: add to d_fix instead of overwriting it */
+
+typedef struct {
+    uint64_t samples;            /* pixel-samples finished                          */
+    uint64_t rays_traced;        /* HittableList::hit calls (mod.rs:56)             */
+    uint64_t sphere_tests;       /* rays_traced * n_spheres (sphere.rs:16 calls)    */
+    uint64_t candidates;         /* tests that reached the sqrt (sphere.rs:26)      */
+    float    kernel_ms;          /* render kernel, HIP events on its stream         */
+    int32_t  n_spheres;
+    int32_t  grid_blocks, block_threads;
+} rt_stats;
+
+/* ---- lifetime -------------------------------------------------------------- */
+
+/* Opens HIP device `device_id`.  Fails with RT_ERR_NO_DEVICE when there is no
+ * HIP device or it is not gfx950 -- there is no fallback path. */
+int rt_create(int32_t device_id, rt_context **out);
+int rt_destroy(rt_context *ctx);
+
+/* ---- scene: stands in for `&world` captured at main.rs:135 ----------------- */
+int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n);
+
+/* Rows owned by (shard_index, shard_count, tile_rows) of an image `height`
+ * rows tall; and the image row j of compact row r. */
+int rt_shard_rows(const rt_params *p, int32_t *out_rows);
+int rt_shard_row_index(const rt_params *p, int32_t compact_row, int32_t *out_j);
+
+/* ---- the hot path: main.rs:122-139 up to (not including) to_rgba ----------- */
+
+/* Host-buffer form.  out_sum: [rows][width][3] f32 radiance SUMS over the spp
+ * samples (divide by spp for the mean), rows = rt_shard_rows().  out_fix
+ * (optional, may be NULL): the exact sums, u64 with quantum 2^-32.
+ * Synchronous. */
+int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *p,
+              float *out_sum, uint64_t *out_fix, rt_stats *stats);
+
+/* Device-buffer form, asynchronous on `stream` (a hipStream_t, or NULL for the
+ * default stream).  d_fix: device pointer to [rows][width][3] u64. */
+int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p,
+                     void *d_fix, void *stream);
+
+/* Exact sums -> f32 sums, on the device (count = rows*width*3 values). */
+int rt_fix_to_f32_device(rt_context *ctx, const void *d_fix, int64_t count,
+                         void *d_out_f32, void *stream);
+
+/* Waits for the context's last launch and returns its counters and time. */
+int rt_last_stats(rt_context *ctx, rt_stats *stats);
+
+/* ---- Color::to_rgba (vec3.rs:403-421) + the row flip (main.rs:141-145) ----- */
+
+/* d_sum: device [rows][width][3] f32 sums; d_rgba: device [rows][width][4] u8.
+ * spp = total samples in the sums.  flip != 0 writes row r at rows-1-r, which
+ * for a whole image is the top-to-bottom order main.rs:141-145 produces. */
+int rt_resolve_rgba8_device(rt_context *ctx, const void *d_sum, int32_t width, int32_t rows,
+                            int64_t spp, int32_t flip, void *d_rgba, void *stream);
+/* Host-buffer form (copies in, resolves on the device, copies out). */
+int rt_resolve_rgba8(rt_context *ctx, const float *sum, int32_t width, int32_t rows,
+                     int64_t spp, int32_t flip, uint8_t *out_rgba);
+
+/* ---- misc ------------------------------------------------------------------ */
+const char *rt_last_error(void);
+const char *rt_backend_name(void);     /* "hip-gfx950" */
+int32_t rt_abi_version(void);
+/* Philox4x32-10 block computed ON THE DEVICE (known-answer test hook). */
+int rt_philox_device(rt_context *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,95 @@
+/*
+ * oracle_common.h -- TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * The random stream both oracles (and the HIP kernel, independently
+ * implemented in rtiow_amd/csrc) consume.  The reference draws from
+ * rand::thread_rng() (main.rs:60,128; vec3.rs:22,27,61; materials.rs:95),
+ * which is OS seeded and unreproducible; what is kept is the DISTRIBUTION of
+ * each draw and the ORDER of draws.
+ *
+ * Stream addressing:
+ *   key     = (seed lo32, seed hi32)
+ *   counter = (pixel index j*W+i, sample index, event index, 0)
+ * One Philox4x32-10 block per "event":
+ *   event 0 of a sample       -> words (0,1,2,3) = (u jitter, v jitter, lens x, lens y)
+ *   every further lens retry  -> words (0,1)     = (lens x, lens y)
+ *   unit-sphere rejection try -> words (0,1,2)   = (x, y, z)
+ *   Dialectric reflectance    -> word  0
+ * A 32-bit word w becomes the uniform u = (w >> 8) * 2^-24 in [0,1): exactly
+ * representable in f32 and f64, so A and B consume identical numbers.
+ */
+#ifndef RTIOW_ORACLE_COMMON_H
+#define RTIOW_ORACLE_COMMON_H
+
+#include <stdint.h>
+#include "oracle.h"
+
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+
+static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                 uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += PHILOX_W0; k1 += PHILOX_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* Event stream of one (pixel, sample).  `explicit_u` (unit tests only)
+ * replaces the Philox words by a caller-supplied list of uniforms. */
+typedef struct {
+    uint32_t k0, k1, pixel, sample, event;
+    const double *explicit_u;
+    int explicit_n, explicit_used;
+} oracle_rng;
+
+static inline void rng_init(oracle_rng *r, uint64_t seed, uint32_t pixel, uint32_t sample)
+{
+    r->k0 = (uint32_t)seed; r->k1 = (uint32_t)(seed >> 32);
+    r->pixel = pixel; r->sample = sample; r->event = 0;
+    r->explicit_u = 0; r->explicit_n = 0; r->explicit_used = 0;
+}
+
+/* Next event: fills `count` uniforms (as doubles holding k*2^-24 values). */
+static inline void rng_event(oracle_rng *r, int count, double *u)
+{
+    if (r->explicit_u) {
+        for (int i = 0; i < count; ++i) {
+            u[i] = (r->explicit_used < r->explicit_n) ? r->explicit_u[r->explicit_used] : 0.0;
+            r->explicit_used++;
+        }
+        return;
+    }
+    uint32_t w[4];
+    philox4x32_10(r->pixel, r->sample, r->event, 0u, r->k0, r->k1, w);
+    r->event++;
+    for (int i = 0; i < count; ++i)
+        u[i] = (double)(w[i] >> 8) * (1.0 / 16777216.0);
+}
+
+/* Row list of a call: rows j = row_begin, row_begin+row_step, ... < row_end. */
+static inline int params_rows(const oracle_params *p)
+{
+    int step = p->row_step > 0 ? p->row_step : 1;
+    if (p->row_end <= p->row_begin) return 0;
+    return (p->row_end - p->row_begin + step - 1) / step;
+}
+
+/* Runs fn(arg, row_slot) for row_slot in [0, nrows) on nthreads workers that
+ * pull rows from an atomic counter -- the analogue of rayon's into_par_iter
+ * over rows (main.rs:122-123).  Defined in oracle_threads.c. */
+typedef void (*oracle_row_fn)(void *arg, int row_slot, int worker);
+int oracle_parallel_rows(int nrows, int nthreads, oracle_row_fn fn, void *arg);
+double oracle_now_seconds(void);
+
+#endif

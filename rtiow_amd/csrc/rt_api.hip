@@ -1,0 +1,417 @@
+// rt_api.hip -- host runtime behind include/rtiow_hip.h (C ABI of librtiow_hip.so).
+//
+// Owns the device-side scene, the work counter, the statistics words and the
+// HIP events of one context; validates parameters; launches the persistent
+// render kernel.  No CPU fallback: every entry point needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "rtiow_hip.h"
+#include "rt_kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define RT_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP,        \
+                        "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    return atoi(v);
+}
+
+} // namespace
+
+struct rt_context {
+    int device = 0;
+    int cu_count = 0;
+    float4 *d_geom = nullptr, *d_mat0 = nullptr, *d_mat1 = nullptr;
+    int n_spheres = -1;
+    unsigned int *d_queue = nullptr;
+    unsigned long long *d_stats = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t own_stream = nullptr;
+    bool launched = false;
+    rt_stats last{};
+    // staging for the host-buffer entry points
+    void *d_stage_fix = nullptr; size_t stage_fix_bytes = 0;
+    void *d_stage_sum = nullptr; size_t stage_sum_bytes = 0;
+    void *d_stage_rgba = nullptr; size_t stage_rgba_bytes = 0;
+    int scan_mode = 1;
+    int blocks_per_cu = 0;     // 0 = occupancy query
+    int chunk = 0;             // 0 = default
+};
+
+namespace {
+
+int validate_params(const rt_params *p)
+{
+    if (!p) return fail(RT_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (p->width < 2 || p->height < 2)
+        return fail(RT_ERR_INVALID_ARGUMENT, "width and height must be >= 2 (u,v divide by W-1,H-1; main.rs:131-132)");
+    if ((long long)p->width * p->height > 0x7fffffffLL)
+        return fail(RT_ERR_INVALID_ARGUMENT, "width*height does not fit the 32-bit Philox pixel counter");
+    if (p->spp < 0 || p->sample_begin < 0 || (long long)p->spp + p->sample_begin > 0x7fffffffLL)
+        return fail(RT_ERR_INVALID_ARGUMENT, "spp/sample_begin out of range");
+    if (p->max_depth < 0) return fail(RT_ERR_INVALID_ARGUMENT, "max_depth must be >= 0");
+    if (!(p->t_min > 0.0f)) return fail(RT_ERR_INVALID_ARGUMENT, "t_min must be > 0 (reference: 1e-4, main.rs:44)");
+    if (p->tile_rows < 1) return fail(RT_ERR_INVALID_ARGUMENT, "tile_rows must be >= 1");
+    if (p->shard_count < 1 || p->shard_index < 0 || p->shard_index >= p->shard_count)
+        return fail(RT_ERR_INVALID_ARGUMENT, "need 0 <= shard_index < shard_count");
+    return RT_OK;
+}
+
+// rows owned by a shard: tiles t = shard_index, shard_index+shard_count, ...
+int shard_rows(const rt_params *p)
+{
+    const long long T = p->tile_rows, H = p->height;
+    const long long ntiles = (H + T - 1) / T;
+    long long rows = 0;
+    for (long long t = p->shard_index; t < ntiles; t += p->shard_count) {
+        const long long lo = t * T;
+        rows += (lo + T <= H) ? T : (H - lo);
+    }
+    return (int)rows;
+}
+
+int ensure(void **ptr, size_t *have, size_t need)
+{
+    if (*have >= need && *ptr) return RT_OK;
+    if (*ptr) { (void)hipFree(*ptr); *ptr = nullptr; *have = 0; }
+    RT_HIP(hipMalloc(ptr, need ? need : 16));
+    *have = need;
+    return RT_OK;
+}
+
+template <int MODE>
+int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, int *grid_out)
+{
+    int per_cu = ctx->blocks_per_cu;
+    if (per_cu <= 0) {
+        int occ = 0;
+        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rt::render_kernel<MODE>, rt::kBlock, 0));
+        per_cu = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
+    }
+    // persistent grid, but never more lanes than there are work items
+    long long grid = (long long)ctx->cu_count * per_cu;
+    const long long need = ((long long)kp.total_items + rt::kBlock - 1) / rt::kBlock;
+    if (grid > need) grid = need;
+    if (grid < 1) grid = 1;
+    *grid_out = (int)grid;
+    RT_HIP(hipEventRecord(ctx->ev0, stream));
+    hipLaunchKernelGGL(rt::render_kernel<MODE>, dim3((unsigned)grid), dim3(rt::kBlock), 0, stream, kp);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipEventRecord(ctx->ev1, stream));
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_err; }
+const char *rt_backend_name(void) { return "hip-gfx950"; }
+int32_t rt_abi_version(void) { return RTIOW_HIP_ABI_VERSION; }
+
+int rt_create(int32_t device_id, rt_context **out)
+{
+    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(RT_ERR_NO_DEVICE, "no HIP device visible (%s); librtiow_hip has no CPU fallback",
+                    e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= count)
+        return fail(RT_ERR_INVALID_ARGUMENT, "device_id %d out of range [0,%d)", device_id, count);
+    RT_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    RT_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RT_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only",
+                    device_id, prop.gcnArchName);
+    rt_context *ctx = new (std::nothrow) rt_context();
+    if (!ctx) return fail(RT_ERR_OUT_OF_MEMORY, "host allocation failed");
+    ctx->device = device_id;
+    ctx->cu_count = prop.multiProcessorCount;
+    ctx->scan_mode = env_int("RTIOW_SCAN_MODE", 1);
+    ctx->blocks_per_cu = env_int("RTIOW_BLOCKS_PER_CU", 0);
+    ctx->chunk = env_int("RTIOW_CHUNK", 0);
+    hipError_t e1 = hipMalloc((void **)&ctx->d_queue, 64);
+    hipError_t e2 = hipMalloc((void **)&ctx->d_stats, 64);
+    hipError_t e3 = hipEventCreate(&ctx->ev0);
+    hipError_t e4 = hipEventCreate(&ctx->ev1);
+    hipError_t e5 = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
+        rt_destroy(ctx);
+        return fail(RT_ERR_HIP, "context setup failed on device %d", device_id);
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+int rt_destroy(rt_context *ctx)
+{
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat0); (void)hipFree(ctx->d_mat1);
+    (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_stats);
+    (void)hipFree(ctx->d_stage_fix); (void)hipFree(ctx->d_stage_sum); (void)hipFree(ctx->d_stage_rgba);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return RT_OK;
+}
+
+int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
+{
+    if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (n < 0 || (n > 0 && !spheres)) return fail(RT_ERR_INVALID_ARGUMENT, "bad sphere list");
+    if (n > 65535) return fail(RT_ERR_INVALID_ARGUMENT, "at most 65535 spheres (16-bit candidate indices)");
+    for (int i = 0; i < n; ++i)
+        if (spheres[i].kind < RT_LAMBERTIAN || spheres[i].kind > RT_DIALECTRIC)
+            return fail(RT_ERR_INVALID_ARGUMENT, "sphere %d: unknown material kind %d", i, spheres[i].kind);
+    RT_HIP(hipSetDevice(ctx->device));
+    // the previous scene may still be in use by a launch on any stream
+    RT_HIP(hipDeviceSynchronize());
+    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat0); (void)hipFree(ctx->d_mat1);
+    ctx->d_geom = ctx->d_mat0 = ctx->d_mat1 = nullptr;
+    ctx->n_spheres = -1;
+    const size_t cnt = (size_t)(n > 0 ? n : 1);
+    std::vector<float4> geom(cnt), mat0(cnt), mat1(cnt);
+    for (int i = 0; i < n; ++i) {
+        const rt_sphere &s = spheres[i];
+        // contract C6: r*r and 1/r are per-sphere constants, one rounding each
+        const float r2 = s.radius * s.radius;
+        const float inv_r = 1.0f / s.radius;
+        geom[i] = make_float4(s.center[0], s.center[1], s.center[2], r2);
+        float kind_bits;
+        const int32_t kind = s.kind;
+        memcpy(&kind_bits, &kind, 4);
+        mat0[i] = make_float4(inv_r, kind_bits, s.param, 0.0f);
+        mat1[i] = make_float4(s.albedo[0], s.albedo[1], s.albedo[2], 0.0f);
+    }
+    RT_HIP(hipMalloc((void **)&ctx->d_geom, cnt * sizeof(float4)));
+    RT_HIP(hipMalloc((void **)&ctx->d_mat0, cnt * sizeof(float4)));
+    RT_HIP(hipMalloc((void **)&ctx->d_mat1, cnt * sizeof(float4)));
+    RT_HIP(hipMemcpy(ctx->d_geom, geom.data(), cnt * sizeof(float4), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_mat0, mat0.data(), cnt * sizeof(float4), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_mat1, mat1.data(), cnt * sizeof(float4), hipMemcpyHostToDevice));
+    ctx->n_spheres = n;
+    return RT_OK;
+}
+
+int rt_shard_rows(const rt_params *p, int32_t *out_rows)
+{
+    if (!out_rows) return fail(RT_ERR_INVALID_ARGUMENT, "out_rows is NULL");
+    int rc = validate_params(p);
+    if (rc) return rc;
+    *out_rows = shard_rows(p);
+    return RT_OK;
+}
+
+int rt_shard_row_index(const rt_params *p, int32_t compact_row, int32_t *out_j)
+{
+    if (!out_j) return fail(RT_ERR_INVALID_ARGUMENT, "out_j is NULL");
+    int rc = validate_params(p);
+    if (rc) return rc;
+    if (compact_row < 0 || compact_row >= shard_rows(p))
+        return fail(RT_ERR_INVALID_ARGUMENT, "compact_row out of range");
+    const int lt = compact_row / p->tile_rows;
+    *out_j = (lt * p->shard_count + p->shard_index) * p->tile_rows + (compact_row - lt * p->tile_rows);
+    return RT_OK;
+}
+
+int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, void *d_fix, void *stream_v)
+{
+    if (!ctx || !cam) return fail(RT_ERR_INVALID_ARGUMENT, "ctx/cam is NULL");
+    int rc = validate_params(p);
+    if (rc) return rc;
+    if (ctx->n_spheres < 0) return fail(RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
+    const int rows = shard_rows(p);
+    if (rows > 0 && !d_fix) return fail(RT_ERR_INVALID_ARGUMENT, "d_fix is NULL");
+    RT_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)stream_v;
+
+    const long long npix = (long long)rows * p->width;
+    // samples per work item: small enough for a short tail, large enough that the
+    // item count fits 31 bits
+    int chunk = ctx->chunk > 0 ? ctx->chunk : 8;
+    if (chunk > p->spp) chunk = p->spp > 0 ? p->spp : 1;
+    while (npix * (((long long)p->spp + chunk - 1) / chunk) > 0x7fffffffLL) chunk *= 2;
+    const long long nchunks = p->spp > 0 ? ((long long)p->spp + chunk - 1) / chunk : 0;
+
+    rt::KParams kp;
+    memset(&kp, 0, sizeof(kp));
+    static_assert(sizeof(rt::KCamera) == sizeof(rt_camera), "camera layouts must match");
+    memcpy(&kp.cam, cam, sizeof(rt_camera));
+    kp.width = p->width; kp.height = p->height;
+    kp.spp = p->spp; kp.sample_begin = p->sample_begin; kp.max_depth = p->max_depth;
+    kp.t_min = p->t_min;
+    kp.k0 = (uint32_t)p->seed; kp.k1 = (uint32_t)(p->seed >> 32);
+    kp.tile_rows = p->tile_rows; kp.shard_index = p->shard_index; kp.shard_count = p->shard_count;
+    kp.rows = rows; kp.n_spheres = ctx->n_spheres; kp.chunk = chunk;
+    kp.npix = (uint32_t)npix; kp.total_items = (uint32_t)(npix * nchunks);
+    kp.geom = ctx->d_geom; kp.mat0 = ctx->d_mat0; kp.mat1 = ctx->d_mat1;
+    kp.fix = (unsigned long long *)d_fix;
+    kp.queue = ctx->d_queue; kp.stats = ctx->d_stats;
+
+    if (!(p->flags & RT_FLAG_ACCUMULATE) && npix > 0)
+        RT_HIP(hipMemsetAsync(d_fix, 0, (size_t)npix * 3 * sizeof(unsigned long long), stream));
+    RT_HIP(hipMemsetAsync(ctx->d_queue, 0, 64, stream));
+    RT_HIP(hipMemsetAsync(ctx->d_stats, 0, 64, stream));
+
+    int grid = 0;
+    if (ctx->scan_mode == 0) rc = launch_render<0>(ctx, kp, stream, &grid);
+    else rc = launch_render<1>(ctx, kp, stream, &grid);
+    if (rc) return rc;
+    ctx->launched = true;
+    memset(&ctx->last, 0, sizeof(ctx->last));
+    ctx->last.n_spheres = ctx->n_spheres;
+    ctx->last.grid_blocks = grid;
+    ctx->last.block_threads = rt::kBlock;
+    return RT_OK;
+}
+
+int rt_last_stats(rt_context *ctx, rt_stats *stats)
+{
+    if (!ctx || !stats) return fail(RT_ERR_INVALID_ARGUMENT, "ctx/stats is NULL");
+    if (!ctx->launched) return fail(RT_ERR_INVALID_ARGUMENT, "no launch to report on");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0.0f;
+    RT_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    unsigned long long h[3] = { 0, 0, 0 };
+    RT_HIP(hipMemcpy(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    ctx->last.rays_traced = h[0];
+    ctx->last.samples = h[1];
+    ctx->last.candidates = h[2];
+    ctx->last.sphere_tests = h[0] * (unsigned long long)(ctx->last.n_spheres > 0 ? ctx->last.n_spheres : 0);
+    ctx->last.kernel_ms = ms;
+    *stats = ctx->last;
+    return RT_OK;
+}
+
+int rt_fix_to_f32_device(rt_context *ctx, const void *d_fix, int64_t count, void *d_out_f32, void *stream_v)
+{
+    if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (count < 0 || (count > 0 && (!d_fix || !d_out_f32))) return fail(RT_ERR_INVALID_ARGUMENT, "bad buffers");
+    if (count == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    long long blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(rt::fix_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_v,
+                       (const unsigned long long *)d_fix, (float *)d_out_f32, (long long)count);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_resolve_rgba8_device(rt_context *ctx, const void *d_sum, int32_t width, int32_t rows,
+                            int64_t spp, int32_t flip, void *d_rgba, void *stream_v)
+{
+    if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (width < 1 || rows < 0 || spp < 1) return fail(RT_ERR_INVALID_ARGUMENT, "bad width/rows/spp");
+    if (rows == 0) return RT_OK;
+    if (!d_sum || !d_rgba) return fail(RT_ERR_INVALID_ARGUMENT, "bad buffers");
+    RT_HIP(hipSetDevice(ctx->device));
+    const long long npix = (long long)width * rows;
+    long long blocks = (npix + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    const float scale = 1.0f / (float)spp;             // vec3.rs:409
+    hipLaunchKernelGGL(rt::resolve_rgba8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_v,
+                       (const float *)d_sum, (uint8_t *)d_rgba, (int)width, (int)rows, scale, (int)flip);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *p,
+              float *out_sum, uint64_t *out_fix, rt_stats *stats)
+{
+    if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    int rc = validate_params(p);
+    if (rc) return rc;
+    const int rows = shard_rows(p);
+    const size_t count = (size_t)rows * p->width * 3;
+    if (count > 0 && !out_sum && !out_fix) return fail(RT_ERR_INVALID_ARGUMENT, "no output buffer");
+    RT_HIP(hipSetDevice(ctx->device));
+    rc = ensure(&ctx->d_stage_fix, &ctx->stage_fix_bytes, count * sizeof(uint64_t));
+    if (rc) return rc;
+    rc = ensure(&ctx->d_stage_sum, &ctx->stage_sum_bytes, count * sizeof(float));
+    if (rc) return rc;
+    rt_params q = *p;
+    q.flags &= ~RT_FLAG_ACCUMULATE;                     // host form always starts from zero
+    rc = rt_render_device(ctx, cam, &q, ctx->d_stage_fix, ctx->own_stream);
+    if (rc) return rc;
+    if (out_sum) {
+        rc = rt_fix_to_f32_device(ctx, ctx->d_stage_fix, (int64_t)count, ctx->d_stage_sum, ctx->own_stream);
+        if (rc) return rc;
+        RT_HIP(hipMemcpyAsync(out_sum, ctx->d_stage_sum, count * sizeof(float), hipMemcpyDeviceToHost, ctx->own_stream));
+    }
+    if (out_fix)
+        RT_HIP(hipMemcpyAsync(out_fix, ctx->d_stage_fix, count * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->own_stream));
+    RT_HIP(hipStreamSynchronize(ctx->own_stream));
+    if (stats) return rt_last_stats(ctx, stats);
+    return RT_OK;
+}
+
+int rt_resolve_rgba8(rt_context *ctx, const float *sum, int32_t width, int32_t rows,
+                     int64_t spp, int32_t flip, uint8_t *out_rgba)
+{
+    if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (width < 1 || rows < 0 || spp < 1) return fail(RT_ERR_INVALID_ARGUMENT, "bad width/rows/spp");
+    if (rows == 0) return RT_OK;
+    if (!sum || !out_rgba) return fail(RT_ERR_INVALID_ARGUMENT, "bad buffers");
+    RT_HIP(hipSetDevice(ctx->device));
+    const size_t npix = (size_t)width * rows;
+    int rc = ensure(&ctx->d_stage_sum, &ctx->stage_sum_bytes, npix * 3 * sizeof(float));
+    if (rc) return rc;
+    rc = ensure(&ctx->d_stage_rgba, &ctx->stage_rgba_bytes, npix * 4);
+    if (rc) return rc;
+    RT_HIP(hipMemcpyAsync(ctx->d_stage_sum, sum, npix * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->own_stream));
+    rc = rt_resolve_rgba8_device(ctx, ctx->d_stage_sum, width, rows, spp, flip, ctx->d_stage_rgba, ctx->own_stream);
+    if (rc) return rc;
+    RT_HIP(hipMemcpyAsync(out_rgba, ctx->d_stage_rgba, npix * 4, hipMemcpyDeviceToHost, ctx->own_stream));
+    RT_HIP(hipStreamSynchronize(ctx->own_stream));
+    return RT_OK;
+}
+
+int rt_philox_device(rt_context *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    if (!ctx || !ctr || !key || !out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    RT_HIP(hipSetDevice(ctx->device));
+    int rc = ensure(&ctx->d_stage_rgba, &ctx->stage_rgba_bytes, 64);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rt::philox_kat_kernel, dim3(1), dim3(1), 0, ctx->own_stream,
+                       ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], (uint32_t *)ctx->d_stage_rgba);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemcpyAsync(out, ctx->d_stage_rgba, 16, hipMemcpyDeviceToHost, ctx->own_stream));
+    RT_HIP(hipStreamSynchronize(ctx->own_stream));
+    return RT_OK;
+}
+
+} // extern "C"
