@@ -1,0 +1,88 @@
+"""ctypes binding of librtiow_hip.so (include/rtiow_hip.h).
+
+The library is the only compute backend: there is no Python or CPU fallback.
+Loading fails loudly when the shared object has not been built
+(`python -c "import __graft_entry__ as g; g.build()"` or ./build_lib.sh).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtiow_hip.so")
+
+
+class rt_sphere(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("kind", C.c_int32),
+                ("albedo", C.c_float * 3), ("param", C.c_float)]
+
+
+class rt_camera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("lower_left_corner", C.c_float * 3),
+                ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3),
+                ("u", C.c_float * 3), ("v", C.c_float * 3), ("lens_radius", C.c_float)]
+
+
+class rt_params(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32),
+                ("sample_begin", C.c_int32), ("max_depth", C.c_int32), ("t_min", C.c_float),
+                ("seed", C.c_uint64), ("tile_rows", C.c_int32), ("shard_index", C.c_int32),
+                ("shard_count", C.c_int32), ("flags", C.c_uint32)]
+
+
+class rt_stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("rays_traced", C.c_uint64), ("sphere_tests", C.c_uint64),
+                ("candidates", C.c_uint64), ("kernel_ms", C.c_float), ("n_spheres", C.c_int32),
+                ("grid_blocks", C.c_int32), ("block_threads", C.c_int32)]
+
+
+RT_FLAG_ACCUMULATE = 0x1
+
+# every symbol include/rtiow_hip.h declares: (name, restype, argtypes)
+_VP = C.c_void_p
+SYMBOLS = [
+    ("rt_create", C.c_int, [C.c_int32, C.POINTER(_VP)]),
+    ("rt_destroy", C.c_int, [_VP]),
+    ("rt_upload_scene", C.c_int, [_VP, C.POINTER(rt_sphere), C.c_int32]),
+    ("rt_shard_rows", C.c_int, [C.POINTER(rt_params), C.POINTER(C.c_int32)]),
+    ("rt_shard_row_index", C.c_int, [C.POINTER(rt_params), C.c_int32, C.POINTER(C.c_int32)]),
+    ("rt_render", C.c_int, [_VP, C.POINTER(rt_camera), C.POINTER(rt_params), _VP, _VP, C.POINTER(rt_stats)]),
+    ("rt_render_device", C.c_int, [_VP, C.POINTER(rt_camera), C.POINTER(rt_params), _VP, _VP]),
+    ("rt_fix_to_f32_device", C.c_int, [_VP, _VP, C.c_int64, _VP, _VP]),
+    ("rt_last_stats", C.c_int, [_VP, C.POINTER(rt_stats)]),
+    ("rt_resolve_rgba8_device", C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _VP, _VP]),
+    ("rt_resolve_rgba8", C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _VP]),
+    ("rt_last_error", C.c_char_p, []),
+    ("rt_backend_name", C.c_char_p, []),
+    ("rt_abi_version", C.c_int32, []),
+    ("rt_philox_device", C.c_int, [_VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+]
+
+_lib = None
+
+
+class RtiowHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Returns the loaded library with prototypes set; raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtiowHipError(
+            f"{LIB_PATH} not found: build it with ./build_lib.sh (hipcc --offload-arch=gfx950); "
+            "there is no CPU fallback for the render path")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().rt_last_error().decode("utf-8", "replace")
+        raise RtiowHipError(f"{what} failed ({rc}): {msg}")

@@ -1,0 +1,130 @@
+"""Renderer: the host-side caller of the C ABI (stands in for main.rs:122-147).
+
+Nothing here computes radiance: every pixel comes from librtiow_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .scene import SPHERE_DTYPE
+
+
+def make_params(width, height, spp, *, sample_begin=0, max_depth=50, t_min=1e-4, seed=1,
+                tile_rows=8, shard_index=0, shard_count=1, flags=0):
+    p = _ffi.rt_params()
+    p.width, p.height, p.spp, p.sample_begin = int(width), int(height), int(spp), int(sample_begin)
+    p.max_depth, p.t_min, p.seed = int(max_depth), float(t_min), int(seed)
+    p.tile_rows, p.shard_index, p.shard_count, p.flags = int(tile_rows), int(shard_index), int(shard_count), int(flags)
+    return p
+
+
+def shard_rows(params):
+    lib = _ffi.load()
+    rows = C.c_int32(0)
+    _ffi.check(lib.rt_shard_rows(C.byref(params), C.byref(rows)), "rt_shard_rows")
+    return rows.value
+
+
+def shard_row_indices(params):
+    """Image row j (0 = bottom) of every compact row of the shard."""
+    lib = _ffi.load()
+    n = shard_rows(params)
+    out = np.empty(n, dtype=np.int32)
+    j = C.c_int32(0)
+    for r in range(n):
+        _ffi.check(lib.rt_shard_row_index(C.byref(params), r, C.byref(j)), "rt_shard_row_index")
+        out[r] = j.value
+    return out
+
+
+def stats_dict(st):
+    return {k: getattr(st, k) for k, _ in _ffi.rt_stats._fields_}
+
+
+class Renderer:
+    """One rt_context (one GPU)."""
+
+    def __init__(self, device_id=0):
+        self._lib = _ffi.load()
+        h = C.c_void_p()
+        _ffi.check(self._lib.rt_create(int(device_id), C.byref(h)), "rt_create")
+        self._h = h
+        self.n_spheres = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- scene ---------------------------------------------------------------
+    def upload_scene(self, world):
+        """world: HittableList, or a numpy array of SPHERE_DTYPE records."""
+        flat = world.flatten() if hasattr(world, "flatten") and not isinstance(world, np.ndarray) else world
+        flat = np.ascontiguousarray(flat, dtype=SPHERE_DTYPE)
+        ptr = flat.ctypes.data_as(C.POINTER(_ffi.rt_sphere))
+        _ffi.check(self._lib.rt_upload_scene(self._h, ptr, int(flat.shape[0])), "rt_upload_scene")
+        self.n_spheres = int(flat.shape[0])
+
+    # -- host-buffer render --------------------------------------------------
+    def render(self, cam, params, want_fix=True):
+        """Returns (sum f32 [rows,W,3], fix u64 [rows,W,3] or None, stats dict)."""
+        rc = cam.to_rt_camera() if hasattr(cam, "to_rt_camera") else cam
+        rows = shard_rows(params)
+        out_sum = np.zeros((rows, params.width, 3), dtype=np.float32)
+        out_fix = np.zeros((rows, params.width, 3), dtype=np.uint64) if want_fix else None
+        st = _ffi.rt_stats()
+        _ffi.check(self._lib.rt_render(self._h, C.byref(rc), C.byref(params),
+                                       out_sum.ctypes.data_as(C.c_void_p),
+                                       out_fix.ctypes.data_as(C.c_void_p) if want_fix else None,
+                                       C.byref(st)), "rt_render")
+        return out_sum, out_fix, stats_dict(st)
+
+    # -- device-buffer render (pointers come from e.g. torch tensors) ---------
+    def render_device(self, cam, params, d_fix_ptr, stream=0):
+        rc = cam.to_rt_camera() if hasattr(cam, "to_rt_camera") else cam
+        _ffi.check(self._lib.rt_render_device(self._h, C.byref(rc), C.byref(params),
+                                              C.c_void_p(d_fix_ptr), C.c_void_p(stream)), "rt_render_device")
+
+    def fix_to_f32_device(self, d_fix_ptr, count, d_out_ptr, stream=0):
+        _ffi.check(self._lib.rt_fix_to_f32_device(self._h, C.c_void_p(d_fix_ptr), int(count),
+                                                  C.c_void_p(d_out_ptr), C.c_void_p(stream)), "rt_fix_to_f32_device")
+
+    def resolve_rgba8_device(self, d_sum_ptr, width, rows, spp, flip, d_rgba_ptr, stream=0):
+        _ffi.check(self._lib.rt_resolve_rgba8_device(self._h, C.c_void_p(d_sum_ptr), int(width), int(rows),
+                                                     int(spp), int(flip), C.c_void_p(d_rgba_ptr),
+                                                     C.c_void_p(stream)), "rt_resolve_rgba8_device")
+
+    def last_stats(self):
+        st = _ffi.rt_stats()
+        _ffi.check(self._lib.rt_last_stats(self._h, C.byref(st)), "rt_last_stats")
+        return stats_dict(st)
+
+    # -- to_rgba + flip --------------------------------------------------------
+    def resolve_rgba8(self, sums, spp, flip=True):
+        sums = np.ascontiguousarray(sums, dtype=np.float32)
+        rows, width = sums.shape[0], sums.shape[1]
+        out = np.zeros((rows, width, 4), dtype=np.uint8)
+        _ffi.check(self._lib.rt_resolve_rgba8(self._h, sums.ctypes.data_as(C.c_void_p), width, rows,
+                                              int(spp), int(bool(flip)), out.ctypes.data_as(C.c_void_p)),
+                   "rt_resolve_rgba8")
+        return out
+
+    def philox(self, ctr, key):
+        c = (C.c_uint32 * 4)(*ctr)
+        k = (C.c_uint32 * 2)(*key)
+        o = (C.c_uint32 * 4)()
+        _ffi.check(self._lib.rt_philox_device(self._h, c, k, o), "rt_philox_device")
+        return tuple(int(x) for x in o)
