@@ -22,11 +22,16 @@
  *     (one per GPU) may be used concurrently;
  *   - there is NO CPU fallback: without a usable gfx950 device rt_create fails.
  *
- * Arithmetic.  The path computes in IEEE binary32 under the contract written
- * in DESIGN.md section 4 (oracle/oracle_b_f32.c is its CPU restatement).  A
- * pixel's sum over samples is exact: every sample's radiance is truncated to a
- * 2^-32 grid and summed in an unsigned 64-bit integer, so the result does not
- * depend on how samples are sharded over lanes, launches, passes or GPUs.
+ * Arithmetic.  Results are those of the reference's own f64 arithmetic: every
+ * value that decides or shades a path is computed in IEEE binary64 in the
+ * reference's operation order (no fused multiply-add), so a render equals the
+ * literal CPU restatement (oracle/oracle_f64.c, Oracle B) bit for bit.  f32
+ * is used only as a CONSERVATIVE FILTER in the sphere scan (it may send a
+ * sphere to the exact f64 test needlessly, never the reverse; DESIGN.md
+ * section 5.2).  A pixel's sum over samples is exact: every sample's radiance
+ * is truncated to a 2^-32 grid and summed in an unsigned 64-bit integer, so
+ * the result does not depend on how samples are sharded over lanes, launches,
+ * passes or GPUs.
  */
 #ifndef RTIOW_HIP_H
 #define RTIOW_HIP_H
@@ -53,30 +58,32 @@ typedef enum {
 /* Material kinds: the three `impl Scatter` of materials.rs. */
 enum { RT_LAMBERTIAN = 0, RT_METAL = 1, RT_DIALECTRIC = 2 };
 
-/* One sphere, flattened.  The reference keeps Sphere{center,radius,mat}
- * (shapes/sphere.rs:9-13) and the material structs (materials.rs:9-11,34-37,
- * 64-66) private behind Box<dyn Hit>/Arc<dyn Scatter>, so the host flattens
- * each object where it is pushed (main.rs:64,87,93-99).  LIST ORDER IS PART OF
- * THE INPUT: on equal t the later sphere wins (mod.rs:61-67, sphere.rs:29). */
+/* One sphere, flattened, in the reference's own f64.  The reference keeps
+ * Sphere{center,radius,mat} (shapes/sphere.rs:9-13) and the material structs
+ * (materials.rs:9-11,34-37,64-66) private behind Box<dyn Hit>/Arc<dyn Scatter>,
+ * so the host flattens each object where it is pushed (main.rs:64,87,93-99).
+ * LIST ORDER IS PART OF THE INPUT: on equal t the later sphere wins
+ * (mod.rs:61-67, sphere.rs:29). */
 typedef struct {
-    float center[3];
-    float radius;
+    double center[3];
+    double radius;
+    double albedo[3];    /* Lambertian, Metal                        */
+    double param;        /* Metal: fuzz; Dialectric: ir              */
     int32_t kind;        /* RT_LAMBERTIAN / RT_METAL / RT_DIALECTRIC */
-    float albedo[3];     /* Lambertian, Metal                        */
-    float param;         /* Metal: fuzz; Dialectric: ir              */
-} rt_sphere;             /* 36 bytes */
+    int32_t reserved;    /* 0                                        */
+} rt_sphere;             /* 72 bytes */
 
-/* Camera (camera.rs:4-13) minus `w`, which get_ray never reads.  The host
- * computes it with its Camera::new (camera.rs:17-45) in f64 and rounds. */
+/* Camera (camera.rs:4-13) minus `w`, which get_ray never reads; f64 as in the
+ * reference.  The host computes it with its Camera::new (camera.rs:17-45). */
 typedef struct {
-    float origin[3];
-    float lower_left_corner[3];
-    float horizontal[3];
-    float vertical[3];
-    float u[3];
-    float v[3];
-    float lens_radius;
-} rt_camera;             /* 76 bytes */
+    double origin[3];
+    double lower_left_corner[3];
+    double horizontal[3];
+    double vertical[3];
+    double u[3];
+    double v[3];
+    double lens_radius;
+} rt_camera;             /* 152 bytes */
 
 /* What main.rs:24-28,44 fixes at compile time, plus sharding.
  *
@@ -90,7 +97,7 @@ typedef struct {
     int32_t spp;                 /* samples per pixel rendered by this call :27    */
     int32_t sample_begin;        /* index of the first sample (additive passes)    */
     int32_t max_depth;           /* :28, 50                                        */
-    float   t_min;               /* :44, 1e-4; must be > 0                         */
+    double  t_min;               /* :44, 1e-4; must be > 0                         */
     uint64_t seed;               /* Philox key                                     */
     int32_t tile_rows;           /* >= 1                                           */
     int32_t shard_index;         /* 0 <= shard_index < shard_count                 */
@@ -99,12 +106,14 @@ typedef struct {
 } rt_params;
 
 #define RT_FLAG_ACCUMULATE 0x1u  /* rt_render_device: add to d_fix instead of overwriting it */
+#define RT_FLAG_NO_FILTER  0x2u  /* validation: send EVERY sphere to the exact f64 test     */
 
 typedef struct {
     uint64_t samples;            /* pixel-samples finished                          */
     uint64_t rays_traced;        /* HittableList::hit calls (mod.rs:56)             */
     uint64_t sphere_tests;       /* rays_traced * n_spheres (sphere.rs:16 calls)    */
-    uint64_t candidates;         /* tests that reached the sqrt (sphere.rs:26)      */
+    uint64_t candidates;         /* tests the f32 filter passed on to the f64 test  */
+    uint64_t exact_roots;        /* f64 tests that reached the sqrt (sphere.rs:26)  */
     float    kernel_ms;          /* render kernel, HIP events on its stream         */
     int32_t  n_spheres;
     int32_t  grid_blocks, block_threads;
@@ -148,20 +157,25 @@ int rt_last_stats(rt_context *ctx, rt_stats *stats);
 
 /* ---- Color::to_rgba (vec3.rs:403-421) + the row flip (main.rs:141-145) ----- */
 
-/* d_sum: device [rows][width][3] f32 sums; d_rgba: device [rows][width][4] u8.
- * spp = total samples in the sums.  flip != 0 writes row r at rows-1-r, which
+/* d_fix: device [rows][width][3] exact sums; d_rgba: device [rows][width][4]
+ * u8.  spp = total samples in the sums.  Each channel is (f64)q * 2^-32 put
+ * through vec3.rs:403-421 in f64.  flip != 0 writes row r at rows-1-r, which
  * for a whole image is the top-to-bottom order main.rs:141-145 produces. */
-int rt_resolve_rgba8_device(rt_context *ctx, const void *d_sum, int32_t width, int32_t rows,
+int rt_resolve_rgba8_device(rt_context *ctx, const void *d_fix, int32_t width, int32_t rows,
                             int64_t spp, int32_t flip, void *d_rgba, void *stream);
 /* Host-buffer form (copies in, resolves on the device, copies out). */
-int rt_resolve_rgba8(rt_context *ctx, const float *sum, int32_t width, int32_t rows,
+int rt_resolve_rgba8(rt_context *ctx, const uint64_t *fix, int32_t width, int32_t rows,
                      int64_t spp, int32_t flip, uint8_t *out_rgba);
 
 /* ---- misc ------------------------------------------------------------------ */
 const char *rt_last_error(void);
 const char *rt_backend_name(void);     /* "hip-gfx950" */
 int32_t rt_abi_version(void);
-/* Philox4x32-10 block computed ON THE DEVICE (known-answer test hook). */
+/* Known-answer test hooks, computed ON THE DEVICE:
+ * one Philox4x32-10 block; and elementwise a[i]/b[i] and sqrt(a[i]) in f64 (the
+ * two operations whose correct rounding the bit-exact contract leans on). */
+int rt_f64_div_sqrt_device(rt_context *ctx, const double *a, const double *b, int32_t n,
+                           double *out_div, double *out_sqrt);
 int rt_philox_device(rt_context *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 #ifdef __cplusplus

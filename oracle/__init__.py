@@ -14,20 +14,14 @@ LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 
 class sphere(C.Structure):
-    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("kind", C.c_int32),
-                ("albedo", C.c_float * 3), ("param", C.c_float)]
+    _fields_ = [("center", C.c_double * 3), ("radius", C.c_double), ("albedo", C.c_double * 3),
+                ("param", C.c_double), ("kind", C.c_int32), ("reserved", C.c_int32)]
 
 
-class camera_f64(C.Structure):
+class camera(C.Structure):
     _fields_ = [("origin", C.c_double * 3), ("lower_left_corner", C.c_double * 3),
                 ("horizontal", C.c_double * 3), ("vertical", C.c_double * 3),
                 ("u", C.c_double * 3), ("v", C.c_double * 3), ("lens_radius", C.c_double)]
-
-
-class camera_f32(C.Structure):
-    _fields_ = [("origin", C.c_float * 3), ("lower_left_corner", C.c_float * 3),
-                ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3),
-                ("u", C.c_float * 3), ("v", C.c_float * 3), ("lens_radius", C.c_float)]
 
 
 class params(C.Structure):
@@ -58,33 +52,24 @@ def load():
         build()
     lib = C.CDLL(LIB_PATH)
     d3 = C.POINTER(C.c_double)
-    f3 = C.POINTER(C.c_float)
     lib.oracle_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
-    lib.oracle_camera_new.argtypes = [d3, d3, d3, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(camera_f64)]
-    lib.oracle_camera_to_f32.argtypes = [C.POINTER(camera_f64), C.POINTER(camera_f32)]
-    lib.oracle_a_render.argtypes = [C.POINTER(camera_f64), C.POINTER(sphere), C.c_int32, C.POINTER(params), C.c_void_p, C.POINTER(stats)]
-    lib.oracle_b_render.argtypes = [C.POINTER(camera_f32), C.POINTER(sphere), C.c_int32, C.POINTER(params), C.c_void_p, C.c_void_p, C.POINTER(stats)]
+    lib.oracle_camera_new.argtypes = [d3, d3, d3, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(camera)]
+    lib.oracle_a_render.argtypes = [C.POINTER(camera), C.POINTER(sphere), C.c_int32, C.POINTER(params), C.c_void_p, C.POINTER(stats)]
+    lib.oracle_b_render.argtypes = [C.POINTER(camera), C.POINTER(sphere), C.c_int32, C.POINTER(params), C.c_void_p, C.c_void_p, C.POINTER(stats)]
     lib.oracle_a_resolve_rgba8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]
     lib.oracle_b_resolve_rgba8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]
     lib.oracle_b_fix_to_f32.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
-    lib.oracle_a_sphere_hit.argtypes = [d3, C.c_double, d3, d3, C.c_double, C.c_double, d3, d3, d3, C.POINTER(C.c_int)]
-    lib.oracle_b_sphere_hit.argtypes = [f3, C.c_float, f3, f3, C.c_float, C.c_float, f3, f3, f3, C.POINTER(C.c_int)]
-    lib.oracle_a_world_hit.argtypes = [C.POINTER(sphere), C.c_int32, d3, d3, C.c_double, d3]
-    lib.oracle_b_world_hit.argtypes = [C.POINTER(sphere), C.c_int32, f3, f3, C.c_float, f3]
-    lib.oracle_a_reflect.argtypes = [d3, d3, d3]
-    lib.oracle_a_refract.argtypes = [d3, d3, C.c_double, d3]
-    lib.oracle_a_reflectance.argtypes = [C.c_double, C.c_double]
-    lib.oracle_a_reflectance.restype = C.c_double
-    lib.oracle_b_reflect.argtypes = [f3, f3, f3]
-    lib.oracle_b_refract.argtypes = [f3, f3, C.c_float, f3]
-    lib.oracle_b_reflectance.argtypes = [C.c_float, C.c_float]
-    lib.oracle_b_reflectance.restype = C.c_float
-    lib.oracle_a_scatter.argtypes = [C.POINTER(sphere), d3, d3, d3, C.c_int, d3, C.c_int, C.POINTER(C.c_int), d3, d3]
-    lib.oracle_b_scatter.argtypes = [C.POINTER(sphere), f3, f3, f3, C.c_int, f3, C.c_int, C.POINTER(C.c_int), f3, f3]
-    lib.oracle_a_to_rgba.argtypes = [d3, C.c_int64, C.POINTER(C.c_uint8)]
-    lib.oracle_b_to_rgba.argtypes = [f3, C.c_int64, C.POINTER(C.c_uint8)]
-    lib.oracle_b_quantize.argtypes = [C.c_float]
+    lib.oracle_b_quantize.argtypes = [C.c_double]
     lib.oracle_b_quantize.restype = C.c_uint64
+    lib.oracle_sphere_hit.argtypes = [d3, C.c_double, d3, d3, C.c_double, C.c_double, d3, d3, d3, C.POINTER(C.c_int)]
+    lib.oracle_world_hit.argtypes = [C.POINTER(sphere), C.c_int32, d3, d3, C.c_double, d3]
+    lib.oracle_reflect.argtypes = [d3, d3, d3]
+    lib.oracle_refract.argtypes = [d3, d3, C.c_double, d3]
+    lib.oracle_reflectance.argtypes = [C.c_double, C.c_double]
+    lib.oracle_reflectance.restype = C.c_double
+    lib.oracle_scatter.argtypes = [C.POINTER(sphere), d3, d3, d3, C.c_int, d3, C.c_int, C.POINTER(C.c_int), d3, d3]
+    lib.oracle_to_rgba.argtypes = [d3, C.c_int64, C.POINTER(C.c_uint8)]
+    lib.oracle_get_ray.argtypes = [C.POINTER(camera), C.c_double, C.c_double, C.c_double, C.c_double, d3, d3]
     lib.oracle_hardware_threads.restype = C.c_int
     _lib = lib
     return lib
@@ -96,10 +81,6 @@ def _d3(v):
     return (C.c_double * 3)(*[float(x) for x in v])
 
 
-def _f3(v):
-    return (C.c_float * 3)(*[float(x) for x in v])
-
-
 def philox(ctr, key):
     o = (C.c_uint32 * 4)()
     load().oracle_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), o)
@@ -107,7 +88,7 @@ def philox(ctr, key):
 
 
 def camera_new(look_from, look_at, v_up, v_fov, aspect_ratio, aperture, focus_dist):
-    c = camera_f64()
+    c = camera()
     load().oracle_camera_new(_d3(look_from), _d3(look_at), _d3(v_up), v_fov, aspect_ratio, aperture, focus_dist, C.byref(c))
     return c
 
@@ -115,12 +96,6 @@ def camera_new(look_from, look_at, v_up, v_fov, aspect_ratio, aperture, focus_di
 def book1_camera(width, height):
     """main.rs:108-118 with aspect = width/height."""
     return camera_new((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, float(width) / float(height), 0.1, 10.0)
-
-
-def camera_to_f32(c64):
-    c = camera_f32()
-    load().oracle_camera_to_f32(C.byref(c64), C.byref(c))
-    return c
 
 
 def make_params(width, height, spp, *, sample_begin=0, max_depth=50, rows=None, seed=1, t_min=1e-4, nthreads=0):
@@ -140,7 +115,7 @@ def n_rows(p):
 
 def _spheres_ptr(flat):
     flat = np.ascontiguousarray(flat)
-    assert flat.dtype.itemsize == 36
+    assert flat.dtype.itemsize == 72
     return flat, flat.ctypes.data_as(C.POINTER(sphere)), int(flat.shape[0])
 
 
@@ -150,23 +125,23 @@ def stats_dict(st):
     return d
 
 
-def render_a(cam64, flat_spheres, p):
-    """Oracle A: returns (sum f64 [rows,W,3], stats)."""
+def render_a(cam, flat_spheres, p):
+    """Oracle A (literal): returns (sum f64 [rows,W,3], stats)."""
     flat, ptr, n = _spheres_ptr(flat_spheres)
     out = np.zeros((n_rows(p), p.width, 3), dtype=np.float64)
     st = stats()
-    rc = load().oracle_a_render(C.byref(cam64), ptr, n, C.byref(p), out.ctypes.data_as(C.c_void_p), C.byref(st))
+    rc = load().oracle_a_render(C.byref(cam), ptr, n, C.byref(p), out.ctypes.data_as(C.c_void_p), C.byref(st))
     assert rc == 0, rc
     return out, stats_dict(st)
 
 
-def render_b(cam32, flat_spheres, p):
-    """Oracle B: returns (fix u64 [rows,W,3], sum f32 [rows,W,3], stats)."""
+def render_b(cam, flat_spheres, p):
+    """Oracle B (kernel contract): returns (fix u64 [rows,W,3], sum f32 [rows,W,3], stats)."""
     flat, ptr, n = _spheres_ptr(flat_spheres)
     fix = np.zeros((n_rows(p), p.width, 3), dtype=np.uint64)
     sm = np.zeros((n_rows(p), p.width, 3), dtype=np.float32)
     st = stats()
-    rc = load().oracle_b_render(C.byref(cam32), ptr, n, C.byref(p), fix.ctypes.data_as(C.c_void_p),
+    rc = load().oracle_b_render(C.byref(cam), ptr, n, C.byref(p), fix.ctypes.data_as(C.c_void_p),
                                 sm.ctypes.data_as(C.c_void_p), C.byref(st))
     assert rc == 0, rc
     return fix, sm, stats_dict(st)
@@ -180,10 +155,10 @@ def resolve_a(sums, spp, flip=True):
     return out
 
 
-def resolve_b(sums, spp, flip=True):
-    sums = np.ascontiguousarray(sums, dtype=np.float32)
-    out = np.zeros((sums.shape[0], sums.shape[1], 4), dtype=np.uint8)
-    load().oracle_b_resolve_rgba8(sums.ctypes.data_as(C.c_void_p), sums.shape[1], sums.shape[0], int(spp), int(flip),
+def resolve_b(fix, spp, flip=True):
+    fix = np.ascontiguousarray(fix, dtype=np.uint64)
+    out = np.zeros((fix.shape[0], fix.shape[1], 4), dtype=np.uint8)
+    load().oracle_b_resolve_rgba8(fix.ctypes.data_as(C.c_void_p), fix.shape[1], fix.shape[0], int(spp), int(flip),
                                   out.ctypes.data_as(C.c_void_p))
     return out
 
@@ -193,3 +168,13 @@ def fix_to_f32(fix):
     out = np.zeros(fix.shape, dtype=np.float32)
     load().oracle_b_fix_to_f32(fix.ctypes.data_as(C.c_void_p), fix.size, out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def camera_from_host(cam):
+    """rtiow_amd.Camera (host mirror) -> oracle camera struct, field by field (no arithmetic)."""
+    c = camera()
+    for name in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v"):
+        a = getattr(cam, name)
+        setattr(c, name, (C.c_double * 3)(float(a[0]), float(a[1]), float(a[2])))
+    c.lens_radius = float(cam.lens_radius)
+    return c

@@ -1,5 +1,5 @@
 /*
- * oracle_a_f64.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
+ * oracle_f64.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
  *
  * Oracle A: LITERAL f64 restatement of the reference hot path.  Recursion,
  * the ordered linear scan, the reference's operation order; compiled with
@@ -7,6 +7,17 @@
  * function cites the reference lines it follows (paths under /root/reference).
  * The only thing that is not the reference's is the source of uniforms
  * (oracle_common.h): same distributions, same draw order.
+ *
+ * Oracle B: the arithmetic contract of the HIP kernel = Oracle A with
+ *   C3  ray_color's recursion (main.rs:38-57) as an iterative bounce loop:
+ *       attenuations multiply into a running throughput left to right and
+ *       the sky colour is multiplied by the throughput at the end;
+ *   C5  an exact pixel sum: each sample's radiance channel x is truncated to
+ *       the 2^-32 grid, q = trunc(clamp(x, 0, 2^30) * 2^32) (NaN -> 0), and
+ *       summed in a u64 (associative: any order or sharding of the samples
+ *       gives the same bits).
+ * B calls the very same sphere_hit / world_hit / scatter / get_ray functions
+ * as A; only ray_color and the accumulation differ.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -189,7 +200,7 @@ static vec3 ray_color(const ray *r, trace_ctx *cx, oracle_rng *rng, int depth)
 }
 
 /* ---- camera.rs:47-54 ------------------------------------------------------ */
-static ray get_ray(const oracle_camera_f64 *c, double s, double t, double lens_x, double lens_y)
+static ray get_ray(const oracle_camera *c, double s, double t, double lens_x, double lens_y)
 {
     vec3 cu = v3(c->u[0], c->u[1], c->u[2]), cv = v3(c->v[0], c->v[1], c->v[2]);
     vec3 origin = v3(c->origin[0], c->origin[1], c->origin[2]);
@@ -204,28 +215,72 @@ static ray get_ray(const oracle_camera_f64 *c, double s, double t, double lens_x
     return r;
 }
 
-/* ---- main.rs:122-139, one pixel sample ------------------------------------ */
-static vec3 sample_pixel(const oracle_camera_f64 *cam, trace_ctx *cx, const oracle_params *p,
-                         int i, int j, int s)
+/* ---- main.rs:131-134: the camera ray of one pixel sample -------------------- */
+static ray sample_ray(const oracle_camera *cam, const oracle_params *p, int i, int j, int s, oracle_rng *rng)
 {
-    oracle_rng rng;
-    rng_init(&rng, p->seed, (uint32_t)j * (uint32_t)p->width + (uint32_t)i, (uint32_t)s);
+    rng_init(rng, p->seed, (uint32_t)j * (uint32_t)p->width + (uint32_t)i, (uint32_t)s);
     double e[4];
-    rng_event(&rng, 4, e);
+    rng_event(rng, 4, e);
     double u = ((double)i + e[0]) / (double)(p->width - 1);    /* main.rs:131 */
     double v = ((double)j + e[1]) / (double)(p->height - 1);   /* main.rs:132 */
     /* random_in_unit_disk, vec3.rs:59-68: gen_range(-1.0..1.0) -> 2u-1 */
     double lx = 2.0 * e[2] - 1.0, ly = 2.0 * e[3] - 1.0;
     while (!(length_squared(v3(lx, ly, 0.0)) < 1.0)) {
-        rng_event(&rng, 2, e);
+        rng_event(rng, 2, e);
         lx = 2.0 * e[0] - 1.0; ly = 2.0 * e[1] - 1.0;
     }
-    ray r = get_ray(cam, u, v, lx, ly);
+    return get_ray(cam, u, v, lx, ly);
+}
+
+/* main.rs:135, Oracle A: recursive ray_color */
+static vec3 sample_pixel(const oracle_camera *cam, trace_ctx *cx, const oracle_params *p,
+                         int i, int j, int s)
+{
+    oracle_rng rng;
+    ray r = sample_ray(cam, p, i, j, s, &rng);
     return ray_color(&r, cx, &rng, p->max_depth);
 }
 
+/* ---- Oracle B: contract C3 (iterative ray_color) ---------------------------- */
+static vec3 ray_color_iter(ray r, trace_ctx *cx, oracle_rng *rng)
+{
+    vec3 thr = v3(1.0, 1.0, 1.0);
+    int depth = cx->max_depth;
+    for (;;) {
+        int k = cx->max_depth - depth;
+        if (depth <= 0) {                                   /* main.rs:40-42 */
+            cx->end_depth++; cx->depth_hist[k < 63 ? k : 63]++;
+            return v3(0.0, 0.0, 0.0);
+        }
+        hit_record rec;
+        cx->rays++;
+        if (!world_hit(cx->world, cx->n, &r, cx->t_min, INFINITY, &rec)) {
+            cx->end_sky++; cx->depth_hist[k < 63 ? k : 63]++;
+            vec3 unit_direction = unit_vector(r.dir);       /* main.rs:54-56 */
+            double t = 0.5 * (unit_direction.y + 1.0);
+            vec3 sky = add(muls(v3(1.0, 1.0, 1.0), 1.0 - t), muls(v3(0.5, 0.7, 1.0), t));
+            return mulv(thr, sky);
+        }
+        vec3 att; ray scat;
+        if (!scatter(&cx->world[rec.mat], &r, &rec, rng, &att, &scat)) {
+            cx->end_absorb++; cx->depth_hist[k < 63 ? k : 63]++;
+            return v3(0.0, 0.0, 0.0);                       /* main.rs:51 */
+        }
+        thr = mulv(thr, att);
+        r = scat;
+        depth -= 1;
+    }
+}
+
+uint64_t oracle_b_quantize(double x)
+{   /* C5 */
+    if (!(x >= 0.0)) return 0;                  /* NaN and negatives */
+    if (x > 1073741824.0) x = 1073741824.0;     /* 2^30 */
+    return (uint64_t)(x * 4294967296.0);        /* exact scaling, truncation */
+}
+
 typedef struct {
-    const oracle_camera_f64 *cam; const sphere64 *world; int n; const oracle_params *p;
+    const oracle_camera *cam; const sphere64 *world; int n; const oracle_params *p;
     double *out; trace_ctx *ctxs;
 } job_a;
 
@@ -250,14 +305,14 @@ static sphere64 *promote_scene(const oracle_sphere *s, int n)
     sphere64 *w = (sphere64 *)malloc(sizeof(sphere64) * (size_t)(n > 0 ? n : 1));
     for (int i = 0; i < n; ++i) {
         w[i].center = v3(s[i].center[0], s[i].center[1], s[i].center[2]);
-        w[i].radius = s[i].radius; w[i].kind = s[i].kind;
+        w[i].radius = s[i].radius; w[i].kind = s[i].kind;   /* f64 in, f64 kept: no rounding */
         w[i].albedo = v3(s[i].albedo[0], s[i].albedo[1], s[i].albedo[2]);
         w[i].param = s[i].param;
     }
     return w;
 }
 
-int oracle_a_render(const oracle_camera_f64 *cam, const oracle_sphere *spheres, int32_t n,
+int oracle_a_render(const oracle_camera *cam, const oracle_sphere *spheres, int32_t n,
                     const oracle_params *p, double *out_sum, oracle_stats *stats)
 {
     if (!cam || !p || !out_sum || n < 0 || p->width < 2 || p->height < 2 || p->spp < 0) return -1;
@@ -288,6 +343,72 @@ int oracle_a_render(const oracle_camera_f64 *cam, const oracle_sphere *spheres, 
     return used < 0 ? -2 : 0;
 }
 
+/* ---- Oracle B driver -------------------------------------------------------- */
+typedef struct {
+    const oracle_camera *cam; const sphere64 *world; int n; const oracle_params *p;
+    uint64_t *out; trace_ctx *ctxs;
+} job_b;
+
+static void row_b(void *arg, int slot, int worker)
+{
+    job_b *jb = (job_b *)arg;
+    const oracle_params *p = jb->p;
+    int step = p->row_step > 0 ? p->row_step : 1;
+    int j = p->row_begin + slot * step;
+    trace_ctx *cx = &jb->ctxs[worker];
+    for (int i = 0; i < p->width; ++i) {
+        uint64_t acc[3] = { 0, 0, 0 };
+        for (int s = p->sample_begin; s < p->sample_begin + p->spp; ++s) {
+            oracle_rng rng;
+            ray r = sample_ray(jb->cam, p, i, j, s, &rng);
+            vec3 c = ray_color_iter(r, cx, &rng);
+            acc[0] += oracle_b_quantize(c.x); acc[1] += oracle_b_quantize(c.y); acc[2] += oracle_b_quantize(c.z);
+        }
+        uint64_t *o = jb->out + ((size_t)slot * p->width + i) * 3;
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+    }
+}
+
+void oracle_b_fix_to_f32(const uint64_t *fix, int64_t count, float *out)
+{   /* (f64)hi*2^32 + (f64)lo (one f64 rounding above 2^53), * 2^-32, to f32 */
+    for (int64_t k = 0; k < count; ++k) {
+        double d = (double)(uint32_t)(fix[k] >> 32) * 4294967296.0 + (double)(uint32_t)fix[k];
+        out[k] = (float)(d * (1.0 / 4294967296.0));
+    }
+}
+
+int oracle_b_render(const oracle_camera *cam, const oracle_sphere *spheres, int32_t n,
+                    const oracle_params *p, uint64_t *out_fix, float *out_sum, oracle_stats *stats)
+{
+    if (!cam || !p || !out_fix || n < 0 || p->width < 2 || p->height < 2 || p->spp < 0) return -1;
+    int nrows = params_rows(p);
+    int nthreads = p->nthreads > 0 ? p->nthreads : oracle_hardware_threads();
+    if (nthreads > 256) nthreads = 256;
+    sphere64 *world = promote_scene(spheres, n);
+    trace_ctx *ctxs = (trace_ctx *)calloc((size_t)nthreads, sizeof(trace_ctx));
+    for (int t = 0; t < nthreads; ++t) {
+        ctxs[t].world = world; ctxs[t].n = n; ctxs[t].t_min = p->t_min; ctxs[t].max_depth = p->max_depth;
+    }
+    job_b jb = { cam, world, n, p, out_fix, ctxs };
+    double t0 = oracle_now_seconds();
+    int used = oracle_parallel_rows(nrows, nthreads, row_b, &jb);
+    double t1 = oracle_now_seconds();
+    if (out_sum) oracle_b_fix_to_f32(out_fix, (int64_t)nrows * p->width * 3, out_sum);
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->samples = (uint64_t)nrows * (uint64_t)p->width * (uint64_t)p->spp;
+        for (int t = 0; t < nthreads; ++t) {
+            stats->rays_traced += ctxs[t].rays;
+            stats->end_sky += ctxs[t].end_sky; stats->end_absorb += ctxs[t].end_absorb;
+            stats->end_depth += ctxs[t].end_depth;
+            for (int k = 0; k < 64; ++k) stats->depth_hist[k] += ctxs[t].depth_hist[k];
+        }
+        stats->seconds = t1 - t0; stats->threads_used = used;
+    }
+    free(ctxs); free(world);
+    return used < 0 ? -2 : 0;
+}
+
 /* ---- vec3.rs:403-421 + row flip main.rs:141-145 ---------------------------- */
 static uint8_t as_u8(double x)
 {   /* Rust `as u8`: saturating, NaN -> 0 */
@@ -302,7 +423,7 @@ static double clamp_r(double x, double lo, double hi)
     if (x > hi) return hi;
     return x;
 }
-void oracle_a_to_rgba(const double c[3], int64_t spp, uint8_t out[4])
+void oracle_to_rgba(const double c[3], int64_t spp, uint8_t out[4])
 {
     double scale = 1.0 / (double)spp;
     for (int k = 0; k < 3; ++k) {
@@ -317,12 +438,12 @@ void oracle_a_resolve_rgba8(const double *sum, int32_t width, int32_t rows, int6
     for (int r = 0; r < rows; ++r) {
         int dst = flip ? rows - 1 - r : r;
         for (int i = 0; i < width; ++i)
-            oracle_a_to_rgba(sum + ((size_t)r * width + i) * 3, spp, out + ((size_t)dst * width + i) * 4);
+            oracle_to_rgba(sum + ((size_t)r * width + i) * 3, spp, out + ((size_t)dst * width + i) * 4);
     }
 }
 
 /* ---- unit-level exports ---------------------------------------------------- */
-int oracle_a_sphere_hit(const double c[3], double radius, const double o[3], const double d[3],
+int oracle_sphere_hit(const double c[3], double radius, const double o[3], const double d[3],
                         double t_min, double t_max, double *t, double p[3], double n[3], int *front)
 {
     ray r = { v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]) };
@@ -333,7 +454,7 @@ int oracle_a_sphere_hit(const double c[3], double radius, const double o[3], con
     n[0] = rec.normal.x; n[1] = rec.normal.y; n[2] = rec.normal.z;
     return 1;
 }
-int oracle_a_world_hit(const oracle_sphere *s, int32_t n, const double o[3], const double d[3],
+int oracle_world_hit(const oracle_sphere *s, int32_t n, const double o[3], const double d[3],
                        double t_min, double *t)
 {
     sphere64 *w = promote_scene(s, n);
@@ -344,19 +465,19 @@ int oracle_a_world_hit(const oracle_sphere *s, int32_t n, const double o[3], con
     free(w);
     return idx;
 }
-void oracle_a_reflect(const double v[3], const double n[3], double out[3])
+void oracle_reflect(const double v[3], const double n[3], double out[3])
 {
     vec3 r = reflect(v3(v[0], v[1], v[2]), v3(n[0], n[1], n[2]));
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
-void oracle_a_refract(const double uv[3], const double n[3], double ratio, double out[3])
+void oracle_refract(const double uv[3], const double n[3], double ratio, double out[3])
 {
     vec3 r = refract(v3(uv[0], uv[1], uv[2]), v3(n[0], n[1], n[2]), ratio);
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
-double oracle_a_reflectance(double cosine, double ref_idx) { return reflectence(cosine, ref_idx); }
+double oracle_reflectance(double cosine, double ref_idx) { return reflectence(cosine, ref_idx); }
 
-int oracle_a_scatter(const oracle_sphere *mat, const double d_in[3], const double p[3],
+int oracle_scatter(const oracle_sphere *mat, const double d_in[3], const double p[3],
                      const double n[3], int front, const double *u, int nu, int *used,
                      double att[3], double d_out[3])
 {
@@ -376,4 +497,27 @@ int oracle_a_scatter(const oracle_sphere *mat, const double d_in[3], const doubl
     d_out[0] = sc.dir.x; d_out[1] = sc.dir.y; d_out[2] = sc.dir.z;
     free(m);
     return ok;
+}
+
+void oracle_b_resolve_rgba8(const uint64_t *fix, int32_t width, int32_t rows, int64_t spp,
+                            int32_t flip, uint8_t *out)
+{
+    for (int r = 0; r < rows; ++r) {
+        int dst = flip ? rows - 1 - r : r;
+        for (int i = 0; i < width; ++i) {
+            const uint64_t *q = fix + ((size_t)r * width + i) * 3;
+            double c[3];
+            for (int k = 0; k < 3; ++k)
+                c[k] = ((double)(uint32_t)(q[k] >> 32) * 4294967296.0 + (double)(uint32_t)q[k]) * (1.0 / 4294967296.0);
+            oracle_to_rgba(c, spp, out + ((size_t)dst * width + i) * 4);
+        }
+    }
+}
+
+void oracle_get_ray(const oracle_camera *cam, double s, double t, double lens_x, double lens_y,
+                    double orig[3], double dir[3])
+{
+    ray r = get_ray(cam, s, t, lens_x, lens_y);
+    orig[0] = r.orig.x; orig[1] = r.orig.y; orig[2] = r.orig.z;
+    dir[0] = r.dir.x; dir[1] = r.dir.y; dir[2] = r.dir.z;
 }

@@ -87,7 +87,7 @@ static void v_unit(const double a[3], double o[3])
 
 void oracle_camera_new(const double look_from[3], const double look_at[3], const double v_up[3],
                        double v_fov_deg, double aspect_ratio, double aperture, double focus_dist,
-                       oracle_camera_f64 *out)
+                       oracle_camera *out)
 {
     /* f64::to_radians multiplies by pi/180 (camera.rs:25). */
     double theta = v_fov_deg * (3.14159265358979323846 / 180.0);
@@ -112,15 +112,3 @@ void oracle_camera_new(const double look_from[3], const double look_at[3], const
     out->lens_radius = aperture / 2.0;
 }
 
-void oracle_camera_to_f32(const oracle_camera_f64 *in, oracle_camera_f32 *out)
-{
-    for (int i = 0; i < 3; ++i) {
-        out->origin[i] = (float)in->origin[i];
-        out->lower_left_corner[i] = (float)in->lower_left_corner[i];
-        out->horizontal[i] = (float)in->horizontal[i];
-        out->vertical[i] = (float)in->vertical[i];
-        out->u[i] = (float)in->u[i];
-        out->v[i] = (float)in->v[i];
-    }
-    out->lens_radius = (float)in->lens_radius;
-}

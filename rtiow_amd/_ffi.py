@@ -12,30 +12,31 @@ LIB_PATH = os.path.join(_HERE, "librtiow_hip.so")
 
 
 class rt_sphere(C.Structure):
-    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("kind", C.c_int32),
-                ("albedo", C.c_float * 3), ("param", C.c_float)]
+    _fields_ = [("center", C.c_double * 3), ("radius", C.c_double), ("albedo", C.c_double * 3),
+                ("param", C.c_double), ("kind", C.c_int32), ("reserved", C.c_int32)]
 
 
 class rt_camera(C.Structure):
-    _fields_ = [("origin", C.c_float * 3), ("lower_left_corner", C.c_float * 3),
-                ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3),
-                ("u", C.c_float * 3), ("v", C.c_float * 3), ("lens_radius", C.c_float)]
+    _fields_ = [("origin", C.c_double * 3), ("lower_left_corner", C.c_double * 3),
+                ("horizontal", C.c_double * 3), ("vertical", C.c_double * 3),
+                ("u", C.c_double * 3), ("v", C.c_double * 3), ("lens_radius", C.c_double)]
 
 
 class rt_params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32),
-                ("sample_begin", C.c_int32), ("max_depth", C.c_int32), ("t_min", C.c_float),
+                ("sample_begin", C.c_int32), ("max_depth", C.c_int32), ("t_min", C.c_double),
                 ("seed", C.c_uint64), ("tile_rows", C.c_int32), ("shard_index", C.c_int32),
                 ("shard_count", C.c_int32), ("flags", C.c_uint32)]
 
 
 class rt_stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays_traced", C.c_uint64), ("sphere_tests", C.c_uint64),
-                ("candidates", C.c_uint64), ("kernel_ms", C.c_float), ("n_spheres", C.c_int32),
+                ("candidates", C.c_uint64), ("exact_roots", C.c_uint64), ("kernel_ms", C.c_float), ("n_spheres", C.c_int32),
                 ("grid_blocks", C.c_int32), ("block_threads", C.c_int32)]
 
 
 RT_FLAG_ACCUMULATE = 0x1
+RT_FLAG_NO_FILTER = 0x2
 
 # every symbol include/rtiow_hip.h declares: (name, restype, argtypes)
 _VP = C.c_void_p
@@ -55,6 +56,7 @@ SYMBOLS = [
     ("rt_backend_name", C.c_char_p, []),
     ("rt_abi_version", C.c_int32, []),
     ("rt_philox_device", C.c_int, [_VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("rt_f64_div_sqrt_device", C.c_int, [_VP, _VP, _VP, C.c_int32, _VP, _VP]),
 ]
 
 _lib = None

@@ -48,7 +48,9 @@ int env_int(const char *name, int dflt)
 struct rt_context {
     int device = 0;
     int cu_count = 0;
-    float4 *d_geom = nullptr, *d_mat0 = nullptr, *d_mat1 = nullptr;
+    float *d_filt = nullptr;       // [n][4] f32 filter records
+    double *d_geo = nullptr;       // [n][4] exact geometry
+    double *d_mat = nullptr;       // [n][6] exact materials
     int n_spheres = -1;
     unsigned int *d_queue = nullptr;
     unsigned long long *d_stats = nullptr;
@@ -60,7 +62,6 @@ struct rt_context {
     void *d_stage_fix = nullptr; size_t stage_fix_bytes = 0;
     void *d_stage_sum = nullptr; size_t stage_sum_bytes = 0;
     void *d_stage_rgba = nullptr; size_t stage_rgba_bytes = 0;
-    int scan_mode = 1;
     int blocks_per_cu = 0;     // 0 = occupancy query
     int chunk = 0;             // 0 = default
 };
@@ -77,7 +78,7 @@ int validate_params(const rt_params *p)
     if (p->spp < 0 || p->sample_begin < 0 || (long long)p->spp + p->sample_begin > 0x7fffffffLL)
         return fail(RT_ERR_INVALID_ARGUMENT, "spp/sample_begin out of range");
     if (p->max_depth < 0) return fail(RT_ERR_INVALID_ARGUMENT, "max_depth must be >= 0");
-    if (!(p->t_min > 0.0f)) return fail(RT_ERR_INVALID_ARGUMENT, "t_min must be > 0 (reference: 1e-4, main.rs:44)");
+    if (!(p->t_min > 0.0)) return fail(RT_ERR_INVALID_ARGUMENT, "t_min must be > 0 (reference: 1e-4, main.rs:44)");
     if (p->tile_rows < 1) return fail(RT_ERR_INVALID_ARGUMENT, "tile_rows must be >= 1");
     if (p->shard_count < 1 || p->shard_index < 0 || p->shard_index >= p->shard_count)
         return fail(RT_ERR_INVALID_ARGUMENT, "need 0 <= shard_index < shard_count");
@@ -106,13 +107,13 @@ int ensure(void **ptr, size_t *have, size_t need)
     return RT_OK;
 }
 
-template <int MODE>
+template <bool FILTERED>
 int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, int *grid_out)
 {
     int per_cu = ctx->blocks_per_cu;
     if (per_cu <= 0) {
         int occ = 0;
-        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rt::render_kernel<MODE>, rt::kBlock, 0));
+        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rt::render_kernel<FILTERED>, rt::kBlock, 0));
         per_cu = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
     }
     // persistent grid, but never more lanes than there are work items
@@ -122,7 +123,7 @@ int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, in
     if (grid < 1) grid = 1;
     *grid_out = (int)grid;
     RT_HIP(hipEventRecord(ctx->ev0, stream));
-    hipLaunchKernelGGL(rt::render_kernel<MODE>, dim3((unsigned)grid), dim3(rt::kBlock), 0, stream, kp);
+    hipLaunchKernelGGL(rt::render_kernel<FILTERED>, dim3((unsigned)grid), dim3(rt::kBlock), 0, stream, kp);
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(ctx->ev1, stream));
     return RT_OK;
@@ -157,7 +158,6 @@ int rt_create(int32_t device_id, rt_context **out)
     if (!ctx) return fail(RT_ERR_OUT_OF_MEMORY, "host allocation failed");
     ctx->device = device_id;
     ctx->cu_count = prop.multiProcessorCount;
-    ctx->scan_mode = env_int("RTIOW_SCAN_MODE", 1);
     ctx->blocks_per_cu = env_int("RTIOW_BLOCKS_PER_CU", 0);
     ctx->chunk = env_int("RTIOW_CHUNK", 0);
     hipError_t e1 = hipMalloc((void **)&ctx->d_queue, 64);
@@ -178,7 +178,7 @@ int rt_destroy(rt_context *ctx)
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
-    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat0); (void)hipFree(ctx->d_mat1);
+    (void)hipFree(ctx->d_filt); (void)hipFree(ctx->d_geo); (void)hipFree(ctx->d_mat);
     (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->d_stage_fix); (void)hipFree(ctx->d_stage_sum); (void)hipFree(ctx->d_stage_rgba);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -193,35 +193,54 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
     if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (n < 0 || (n > 0 && !spheres)) return fail(RT_ERR_INVALID_ARGUMENT, "bad sphere list");
     if (n > 65535) return fail(RT_ERR_INVALID_ARGUMENT, "at most 65535 spheres (16-bit candidate indices)");
-    for (int i = 0; i < n; ++i)
-        if (spheres[i].kind < RT_LAMBERTIAN || spheres[i].kind > RT_DIALECTRIC)
-            return fail(RT_ERR_INVALID_ARGUMENT, "sphere %d: unknown material kind %d", i, spheres[i].kind);
+    for (int i = 0; i < n; ++i) {
+        const rt_sphere &s = spheres[i];
+        if (s.kind < RT_LAMBERTIAN || s.kind > RT_DIALECTRIC)
+            return fail(RT_ERR_INVALID_ARGUMENT, "sphere %d: unknown material kind %d", i, s.kind);
+        const double mags[4] = { s.center[0], s.center[1], s.center[2], s.radius };
+        for (double v : mags)
+            if (!(std::fabs(v) < 1e15))
+                return fail(RT_ERR_INVALID_ARGUMENT, "sphere %d: coordinates/radius must be finite and below 1e15", i);
+    }
     RT_HIP(hipSetDevice(ctx->device));
     // the previous scene may still be in use by a launch on any stream
     RT_HIP(hipDeviceSynchronize());
-    (void)hipFree(ctx->d_geom); (void)hipFree(ctx->d_mat0); (void)hipFree(ctx->d_mat1);
-    ctx->d_geom = ctx->d_mat0 = ctx->d_mat1 = nullptr;
+    (void)hipFree(ctx->d_filt); (void)hipFree(ctx->d_geo); (void)hipFree(ctx->d_mat);
+    ctx->d_filt = nullptr; ctx->d_geo = ctx->d_mat = nullptr;
     ctx->n_spheres = -1;
     const size_t cnt = (size_t)(n > 0 ? n : 1);
-    std::vector<float4> geom(cnt), mat0(cnt), mat1(cnt);
+    std::vector<float> filt(cnt * 4, 0.0f);
+    std::vector<double> geo(cnt * 4, 0.0), mat(cnt * 6, 0.0);
+    const double KU = (double)rt::kFilterKU;
+    const double kappa = KU / (1.0 - KU);
     for (int i = 0; i < n; ++i) {
         const rt_sphere &s = spheres[i];
-        // contract C6: r*r and 1/r are per-sphere constants, one rounding each
-        const float r2 = s.radius * s.radius;
-        const float inv_r = 1.0f / s.radius;
-        geom[i] = make_float4(s.center[0], s.center[1], s.center[2], r2);
-        float kind_bits;
-        const int32_t kind = s.kind;
-        memcpy(&kind_bits, &kind, 4);
-        mat0[i] = make_float4(inv_r, kind_bits, s.param, 0.0f);
-        mat1[i] = make_float4(s.albedo[0], s.albedo[1], s.albedo[2], 0.0f);
+        // exact records: radius*radius (sphere.rs:22) and 1.0/radius (vec3.rs:371-375 applied
+        // at sphere.rs:37) are per-sphere constants, each one f64 rounding, as in the reference
+        const double r2 = s.radius * s.radius;
+        geo[4 * i + 0] = s.center[0]; geo[4 * i + 1] = s.center[1]; geo[4 * i + 2] = s.center[2];
+        geo[4 * i + 3] = r2;
+        mat[6 * i + 0] = 1.0 / s.radius;
+        mat[6 * i + 1] = s.param;
+        mat[6 * i + 2] = s.albedo[0]; mat[6 * i + 3] = s.albedo[1]; mat[6 * i + 4] = s.albedo[2];
+        mat[6 * i + 5] = (double)s.kind;
+        // filter record: centre rounded to f32, radius^2 inflated by kappa (2 r^2 + |c|^2)
+        // and rounded UP (rt_device.hpp)
+        const double c2 = s.center[0] * s.center[0] + s.center[1] * s.center[1] + s.center[2] * s.center[2];
+        const double r2f_exact = (r2 + kappa * (2.0 * r2 + c2)) * (1.0 + 1e-12);
+        float r2f = (float)r2f_exact;
+        if ((double)r2f < r2f_exact) r2f = std::nextafterf(r2f, INFINITY);
+        // spheres too small for f32's normal range are always sent to the exact test
+        if (!(r2 > 1e-30)) r2f = INFINITY;
+        filt[4 * i + 0] = (float)s.center[0]; filt[4 * i + 1] = (float)s.center[1];
+        filt[4 * i + 2] = (float)s.center[2]; filt[4 * i + 3] = r2f;
     }
-    RT_HIP(hipMalloc((void **)&ctx->d_geom, cnt * sizeof(float4)));
-    RT_HIP(hipMalloc((void **)&ctx->d_mat0, cnt * sizeof(float4)));
-    RT_HIP(hipMalloc((void **)&ctx->d_mat1, cnt * sizeof(float4)));
-    RT_HIP(hipMemcpy(ctx->d_geom, geom.data(), cnt * sizeof(float4), hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(ctx->d_mat0, mat0.data(), cnt * sizeof(float4), hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(ctx->d_mat1, mat1.data(), cnt * sizeof(float4), hipMemcpyHostToDevice));
+    RT_HIP(hipMalloc((void **)&ctx->d_filt, cnt * 4 * sizeof(float)));
+    RT_HIP(hipMalloc((void **)&ctx->d_geo, cnt * 4 * sizeof(double)));
+    RT_HIP(hipMalloc((void **)&ctx->d_mat, cnt * 6 * sizeof(double)));
+    RT_HIP(hipMemcpy(ctx->d_filt, filt.data(), cnt * 4 * sizeof(float), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_geo, geo.data(), cnt * 4 * sizeof(double), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_mat, mat.data(), cnt * 6 * sizeof(double), hipMemcpyHostToDevice));
     ctx->n_spheres = n;
     return RT_OK;
 }
@@ -277,7 +296,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.tile_rows = p->tile_rows; kp.shard_index = p->shard_index; kp.shard_count = p->shard_count;
     kp.rows = rows; kp.n_spheres = ctx->n_spheres; kp.chunk = chunk;
     kp.npix = (uint32_t)npix; kp.total_items = (uint32_t)(npix * nchunks);
-    kp.geom = ctx->d_geom; kp.mat0 = ctx->d_mat0; kp.mat1 = ctx->d_mat1;
+    kp.filt = ctx->d_filt; kp.geo = ctx->d_geo; kp.mat = ctx->d_mat;
     kp.fix = (unsigned long long *)d_fix;
     kp.queue = ctx->d_queue; kp.stats = ctx->d_stats;
 
@@ -287,8 +306,8 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     RT_HIP(hipMemsetAsync(ctx->d_stats, 0, 64, stream));
 
     int grid = 0;
-    if (ctx->scan_mode == 0) rc = launch_render<0>(ctx, kp, stream, &grid);
-    else rc = launch_render<1>(ctx, kp, stream, &grid);
+    if (p->flags & RT_FLAG_NO_FILTER) rc = launch_render<false>(ctx, kp, stream, &grid);
+    else rc = launch_render<true>(ctx, kp, stream, &grid);
     if (rc) return rc;
     ctx->launched = true;
     memset(&ctx->last, 0, sizeof(ctx->last));
@@ -306,11 +325,12 @@ int rt_last_stats(rt_context *ctx, rt_stats *stats)
     RT_HIP(hipEventSynchronize(ctx->ev1));
     float ms = 0.0f;
     RT_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    unsigned long long h[3] = { 0, 0, 0 };
+    unsigned long long h[4] = { 0, 0, 0, 0 };
     RT_HIP(hipMemcpy(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost));
     ctx->last.rays_traced = h[0];
     ctx->last.samples = h[1];
     ctx->last.candidates = h[2];
+    ctx->last.exact_roots = h[3];
     ctx->last.sphere_tests = h[0] * (unsigned long long)(ctx->last.n_spheres > 0 ? ctx->last.n_spheres : 0);
     ctx->last.kernel_ms = ms;
     *stats = ctx->last;
@@ -331,20 +351,20 @@ int rt_fix_to_f32_device(rt_context *ctx, const void *d_fix, int64_t count, void
     return RT_OK;
 }
 
-int rt_resolve_rgba8_device(rt_context *ctx, const void *d_sum, int32_t width, int32_t rows,
+int rt_resolve_rgba8_device(rt_context *ctx, const void *d_fix, int32_t width, int32_t rows,
                             int64_t spp, int32_t flip, void *d_rgba, void *stream_v)
 {
     if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (width < 1 || rows < 0 || spp < 1) return fail(RT_ERR_INVALID_ARGUMENT, "bad width/rows/spp");
     if (rows == 0) return RT_OK;
-    if (!d_sum || !d_rgba) return fail(RT_ERR_INVALID_ARGUMENT, "bad buffers");
+    if (!d_fix || !d_rgba) return fail(RT_ERR_INVALID_ARGUMENT, "bad buffers");
     RT_HIP(hipSetDevice(ctx->device));
     const long long npix = (long long)width * rows;
     long long blocks = (npix + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    const float scale = 1.0f / (float)spp;             // vec3.rs:409
+    const double scale = 1.0 / (double)spp;            // vec3.rs:409
     hipLaunchKernelGGL(rt::resolve_rgba8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_v,
-                       (const float *)d_sum, (uint8_t *)d_rgba, (int)width, (int)rows, scale, (int)flip);
+                       (const unsigned long long *)d_fix, (uint8_t *)d_rgba, (int)width, (int)rows, scale, (int)flip);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
@@ -379,23 +399,44 @@ int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *p,
     return RT_OK;
 }
 
-int rt_resolve_rgba8(rt_context *ctx, const float *sum, int32_t width, int32_t rows,
+int rt_resolve_rgba8(rt_context *ctx, const uint64_t *fix, int32_t width, int32_t rows,
                      int64_t spp, int32_t flip, uint8_t *out_rgba)
 {
     if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (width < 1 || rows < 0 || spp < 1) return fail(RT_ERR_INVALID_ARGUMENT, "bad width/rows/spp");
     if (rows == 0) return RT_OK;
-    if (!sum || !out_rgba) return fail(RT_ERR_INVALID_ARGUMENT, "bad buffers");
+    if (!fix || !out_rgba) return fail(RT_ERR_INVALID_ARGUMENT, "bad buffers");
     RT_HIP(hipSetDevice(ctx->device));
     const size_t npix = (size_t)width * rows;
-    int rc = ensure(&ctx->d_stage_sum, &ctx->stage_sum_bytes, npix * 3 * sizeof(float));
+    int rc = ensure(&ctx->d_stage_fix, &ctx->stage_fix_bytes, npix * 3 * sizeof(uint64_t));
     if (rc) return rc;
     rc = ensure(&ctx->d_stage_rgba, &ctx->stage_rgba_bytes, npix * 4);
     if (rc) return rc;
-    RT_HIP(hipMemcpyAsync(ctx->d_stage_sum, sum, npix * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->own_stream));
-    rc = rt_resolve_rgba8_device(ctx, ctx->d_stage_sum, width, rows, spp, flip, ctx->d_stage_rgba, ctx->own_stream);
+    RT_HIP(hipMemcpyAsync(ctx->d_stage_fix, fix, npix * 3 * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->own_stream));
+    rc = rt_resolve_rgba8_device(ctx, ctx->d_stage_fix, width, rows, spp, flip, ctx->d_stage_rgba, ctx->own_stream);
     if (rc) return rc;
     RT_HIP(hipMemcpyAsync(out_rgba, ctx->d_stage_rgba, npix * 4, hipMemcpyDeviceToHost, ctx->own_stream));
+    RT_HIP(hipStreamSynchronize(ctx->own_stream));
+    return RT_OK;
+}
+
+int rt_f64_div_sqrt_device(rt_context *ctx, const double *a, const double *b, int32_t n,
+                           double *out_div, double *out_sqrt)
+{
+    if (!ctx || !a || !b || !out_div || !out_sqrt || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)n * sizeof(double);
+    int rc = ensure(&ctx->d_stage_fix, &ctx->stage_fix_bytes, 4 * bytes);
+    if (rc) return rc;
+    double *da = (double *)ctx->d_stage_fix, *db = da + n, *dq = db + n, *dr = dq + n;
+    RT_HIP(hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, ctx->own_stream));
+    RT_HIP(hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, ctx->own_stream));
+    hipLaunchKernelGGL(rt::f64_div_sqrt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->own_stream,
+                       (const double *)da, (const double *)db, (int)n, dq, dr);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemcpyAsync(out_div, dq, bytes, hipMemcpyDeviceToHost, ctx->own_stream));
+    RT_HIP(hipMemcpyAsync(out_sqrt, dr, bytes, hipMemcpyDeviceToHost, ctx->own_stream));
     RT_HIP(hipStreamSynchronize(ctx->own_stream));
     return RT_OK;
 }

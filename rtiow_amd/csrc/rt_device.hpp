@@ -1,60 +1,59 @@
 // rt_device.hpp -- device-side arithmetic of the render megakernel (gfx950).
 //
-// This file IS the f32 arithmetic contract of DESIGN.md section 4, written for
-// the GPU: binary32 everywhere, correctly rounded + - * / sqrt, subnormals
-// kept, and multiply-adds fused ONLY where __builtin_fmaf is spelled out
-// (the translation unit is compiled with -ffp-contract=off).  Reference lines
-// cited are paths under the upstream repo (src/...).
+// Two kinds of arithmetic live here (DESIGN.md sections 4 and 5.2):
+//
+//  * the EXACT path, in IEEE binary64, in the reference's operation order and
+//    with no fused multiply-add (this translation unit is compiled with
+//    -ffp-contract=off and no f64 fma is ever written out).  It decides every
+//    hit and computes every shading value; it is written to agree with
+//    oracle/oracle_f64.c (Oracle B) bit for bit.  / and sqrt are the correctly
+//    rounded f64 expansions of the compiler.
+//  * the f32 FILTER of the sphere scan, which only ever answers "this sphere
+//    cannot be hit" or "ask the exact path".
+//
+// Reference lines cited are paths under the upstream repo (src/...).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace rt {
 
-struct V3 { float x, y, z; };
+struct D3 { double x, y, z; };
 
-__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ D3 mk(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
+// vec3.rs:137-147, :243-253, :330-356, :358-367
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ D3 operator*(D3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ D3 operator*(D3 a, D3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
 
-// vec3.rs:95-97 / :87-89 as fused chains (contract C2).
-__device__ __forceinline__ float dot(V3 a, V3 b)
-{
-    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
-}
-__device__ __forceinline__ float len2(V3 a) { return dot(a, a); }
-
-// Correctly rounded by -fhip-fp32-correctly-rounded-divide-sqrt (hipcc default,
-// passed explicitly by the build).
-__device__ __forceinline__ float rsqrt_len(V3 a) { return 1.0f / __builtin_sqrtf(len2(a)); }
+// vec3.rs:95-97 and :87-89 (powi(2) = x*x): left-to-right sums of rounded products.
+__device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double length_squared(D3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 // vec3.rs:107-109 with Div<f64> = multiply by the reciprocal (:371-375).
-__device__ __forceinline__ V3 unit_vector(V3 a) { return a * rsqrt_len(a); }
-
+__device__ __forceinline__ D3 unit_vector(D3 a) { return a * (1.0 / __builtin_sqrt(length_squared(a))); }
 // vec3.rs:116-118:  v - (2*dot(v,n)) * n
-__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - n * (2.0f * dot(v, n)); }
-
-__device__ __forceinline__ float min_1(float x) { return (x < 1.0f) ? x : 1.0f; }   // 1.0.min(x), NaN -> 1
+__device__ __forceinline__ D3 reflect(D3 v, D3 n) { return v - n * (2.0 * dot(v, n)); }
+__device__ __forceinline__ double min_1(double x) { return (x < 1.0) ? x : 1.0; }   // 1.0.min(x): NaN -> 1
 
 // vec3.rs:120-125
-__device__ __forceinline__ V3 refract(V3 uv, V3 n, float etai_over_etat)
+__device__ __forceinline__ D3 refract(D3 uv, D3 n, double etai_over_etat)
 {
-    float cos_theta = min_1(-dot(uv, n));
-    V3 perp = (uv + n * cos_theta) * etai_over_etat;
-    V3 par = n * (-__builtin_sqrtf(__builtin_fabsf(1.0f - len2(perp))));
+    const double cos_theta = min_1(-dot(uv, n));
+    const D3 perp = (uv + n * cos_theta) * etai_over_etat;
+    const D3 par = n * (-__builtin_sqrt(__builtin_fabs(1.0 - length_squared(perp))));
     return perp + par;
 }
 
 // materials.rs:78-82; powi(2) = x*x, powi(5) = ((x*x)*(x*x))*x
-__device__ __forceinline__ float reflectance(float cosine, float ref_idx)
+__device__ __forceinline__ double reflectance(double cosine, double ref_idx)
 {
-    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    double r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
     r0 = r0 * r0;
-    float x = 1.0f - cosine;
-    float x2 = x * x;
-    float x5 = (x2 * x2) * x;
-    return r0 + (1.0f - r0) * x5;
+    const double x = 1.0 - cosine;
+    const double x2 = x * x;
+    const double x5 = (x2 * x2) * x;
+    return r0 + (1.0 - r0) * x5;
 }
 
 // ---- Philox4x32-10 (Random123), counter = (pixel, sample, event, 0) ---------
@@ -67,10 +66,10 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
     constexpr uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint64_t p0 = (uint64_t)M0 * c0;      // v_mad_u64_u32: hi and lo in one go
-        uint64_t p1 = (uint64_t)M1 * c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint64_t p0 = (uint64_t)M0 * c0;      // hi and lo of one 32x32 product
+        const uint64_t p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
         c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
         k0 += W0; k1 += W1;
     }
@@ -78,17 +77,63 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
     return o;
 }
 
-// word -> uniform in [0,1): (w >> 8) * 2^-24, exact in f32.
-__device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }
-// gen_range(-1.0..1.0) / (-1.0..=1.0): 2u - 1, exact for 24-bit u.
-__device__ __forceinline__ float u11(uint32_t w) { return 2.0f * u01(w) - 1.0f; }
+// word -> uniform in [0,1): (w >> 8) * 2^-24 (exact).
+__device__ __forceinline__ double u01(uint32_t w) { return (double)(w >> 8) * (1.0 / 16777216.0); }
+// gen_range(-1.0..1.0) / (-1.0..=1.0): 2u - 1 (exact).
+__device__ __forceinline__ double u11(uint32_t w) { return 2.0 * u01(w) - 1.0; }
 
 // Contract C5: truncate one radiance channel to the 2^-32 grid.
-__device__ __forceinline__ unsigned long long quantize(float x)
+__device__ __forceinline__ unsigned long long quantize(double x)
 {
-    if (!(x >= 0.0f)) return 0ull;               // NaN and negatives
-    if (x > 1073741824.0f) x = 1073741824.0f;    // 2^30
-    return (unsigned long long)((double)x * 4294967296.0);
+    if (!(x >= 0.0)) return 0ull;               // NaN and negatives
+    if (x > 1073741824.0) x = 1073741824.0;     // 2^30
+    return (unsigned long long)(x * 4294967296.0);
+}
+
+// ---- the f32 filter of the sphere scan ----------------
+//
+// For a ray (o, d) and a sphere (c, r) the reference rejects when
+//     disc = half_b^2 - a*cc < 0,  half_b = oc.d, a = d.d, cc = oc.oc - r^2  (sphere.rs:18-25).
+// The filter evaluates, in f32,
+//     D = half_b^2 + Bo - a' * (oc.oc - r2f)
+// with  a' = a(1 - KU),  Bo = KU a |o|^2,  r2f >= r^2 + kappa (2 r^2 + |c|^2),
+// kappa = KU/(1-KU), which in exact arithmetic equals
+//     disc + KU a (|oc|^2 + r^2 + |c|^2 + |o|^2).
+// The f32 evaluation of D is off from that by at most 28 u a (|oc|^2+r^2+|c|^2+|o|^2),
+// u = 2^-24 (error analysis in DESIGN.md), and KU = 64 u, so D < 0 implies
+// disc < 0: a sphere the filter drops is one the reference rejects.
+constexpr float kFilterKU = 64.0f * 5.9604644775390625e-08f;           // 2^-18
+
+struct RayFilter {
+    float ox, oy, oz, dx, dy, dz;
+    float a_scaled;     // a' = a (1 - KU)
+    float bo;           // Bo = KU a |o|^2, or +inf when f32 cannot represent the ray safely
+};
+
+__device__ __forceinline__ RayFilter make_filter(D3 o, D3 d)
+{
+    RayFilter f;
+    f.ox = (float)o.x; f.oy = (float)o.y; f.oz = (float)o.z;
+    f.dx = (float)d.x; f.dy = (float)d.y; f.dz = (float)d.z;
+    const float a = __builtin_fmaf(f.dz, f.dz, __builtin_fmaf(f.dy, f.dy, f.dx * f.dx));
+    const float o2 = __builtin_fmaf(f.oz, f.oz, __builtin_fmaf(f.oy, f.oy, f.ox * f.ox));
+    f.a_scaled = a * (1.0f - kFilterKU);
+    f.bo = (kFilterKU * a) * o2;
+    // outside the range where the relative-error analysis holds: let everything through
+    const bool sane = (a > 1e-20f) && (a < 1e20f) && (o2 < 1e30f);
+    if (!sane) f.bo = __builtin_inff();
+    return f;
+}
+
+// true: the sphere cannot be hit (disc < 0 is certain).  NaN compares false -> candidate.
+__device__ __forceinline__ bool filter_rejects(const RayFilter &f, float cx, float cy, float cz, float r2f)
+{
+    const float ocx = f.ox - cx, ocy = f.oy - cy, ocz = f.oz - cz;
+    const float hb = __builtin_fmaf(ocz, f.dz, __builtin_fmaf(ocy, f.dy, ocx * f.dx));
+    const float cc = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -r2f)));
+    const float t = __builtin_fmaf(hb, hb, f.bo);
+    const float D = __builtin_fmaf(-f.a_scaled, cc, t);
+    return D < 0.0f;
 }
 
 } // namespace rt

@@ -102,8 +102,8 @@ class Renderer:
         _ffi.check(self._lib.rt_fix_to_f32_device(self._h, C.c_void_p(d_fix_ptr), int(count),
                                                   C.c_void_p(d_out_ptr), C.c_void_p(stream)), "rt_fix_to_f32_device")
 
-    def resolve_rgba8_device(self, d_sum_ptr, width, rows, spp, flip, d_rgba_ptr, stream=0):
-        _ffi.check(self._lib.rt_resolve_rgba8_device(self._h, C.c_void_p(d_sum_ptr), int(width), int(rows),
+    def resolve_rgba8_device(self, d_fix_ptr, width, rows, spp, flip, d_rgba_ptr, stream=0):
+        _ffi.check(self._lib.rt_resolve_rgba8_device(self._h, C.c_void_p(d_fix_ptr), int(width), int(rows),
                                                      int(spp), int(flip), C.c_void_p(d_rgba_ptr),
                                                      C.c_void_p(stream)), "rt_resolve_rgba8_device")
 
@@ -113,14 +113,26 @@ class Renderer:
         return stats_dict(st)
 
     # -- to_rgba + flip --------------------------------------------------------
-    def resolve_rgba8(self, sums, spp, flip=True):
-        sums = np.ascontiguousarray(sums, dtype=np.float32)
-        rows, width = sums.shape[0], sums.shape[1]
+    def resolve_rgba8(self, fix, spp, flip=True):
+        """fix: exact sums u64 [rows,W,3] -> RGBA8 [rows,W,4] (vec3.rs:403-421, main.rs:141-145)."""
+        fix = np.ascontiguousarray(fix, dtype=np.uint64)
+        rows, width = fix.shape[0], fix.shape[1]
         out = np.zeros((rows, width, 4), dtype=np.uint8)
-        _ffi.check(self._lib.rt_resolve_rgba8(self._h, sums.ctypes.data_as(C.c_void_p), width, rows,
+        _ffi.check(self._lib.rt_resolve_rgba8(self._h, fix.ctypes.data_as(C.c_void_p), width, rows,
                                               int(spp), int(bool(flip)), out.ctypes.data_as(C.c_void_p)),
                    "rt_resolve_rgba8")
         return out
+
+    def f64_div_sqrt(self, a, b):
+        """Device-side a/b and sqrt(a) in f64 (known-answer test hook)."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        q = np.zeros_like(a)
+        r = np.zeros_like(a)
+        _ffi.check(self._lib.rt_f64_div_sqrt_device(self._h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                                    int(a.size), q.ctypes.data_as(C.c_void_p),
+                                                    r.ctypes.data_as(C.c_void_p)), "rt_f64_div_sqrt_device")
+        return q, r
 
     def philox(self, ctr, key):
         c = (C.c_uint32 * 4)(*ctr)

@@ -9,7 +9,7 @@ Same names as the reference (including its spelling `Dialectric`):
 
 The reference keeps sphere and material fields private behind trait objects,
 so a GPU backend cannot read them back; here every object also knows how to
-flatten itself into the 36-byte rt_sphere record of include/rtiow_hip.h.
+flatten itself into the 72-byte (all-f64) rt_sphere record of include/rtiow_hip.h.
 """
 import math
 
@@ -20,9 +20,9 @@ from .philox import UniformStream
 
 RT_LAMBERTIAN, RT_METAL, RT_DIALECTRIC = 0, 1, 2
 
-SPHERE_DTYPE = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("kind", "<i4"),
-                         ("albedo", "<f4", 3), ("param", "<f4")])
-assert SPHERE_DTYPE.itemsize == 36
+SPHERE_DTYPE = np.dtype([("center", "<f8", 3), ("radius", "<f8"), ("albedo", "<f8", 3),
+                         ("param", "<f8"), ("kind", "<i4"), ("reserved", "<i4")])
+assert SPHERE_DTYPE.itemsize == 72
 
 
 def Vec3(x, y, z):
@@ -67,7 +67,7 @@ class Camera:
         c = _ffi.rt_camera()
         for name in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v"):
             a = getattr(self, name)
-            setattr(c, name, (_ffi.C.c_float * 3)(float(a[0]), float(a[1]), float(a[2])))
+            setattr(c, name, (_ffi.C.c_double * 3)(float(a[0]), float(a[1]), float(a[2])))
         c.lens_radius = float(self.lens_radius)
         return c
 
