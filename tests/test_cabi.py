@@ -1,0 +1,75 @@
+"""The C-ABI shared library: it loads, exports every symbol include/rtiow_hip.h
+declares, validates arguments, and has NO CPU fallback (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from rtiow_amd import _ffi
+import rtiow_amd as rt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "rtiow_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _ffi.load()
+    names = header_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/rtiow_hip.h but not exported"
+    assert sorted(n for n, _, _ in _ffi.SYMBOLS) == names      # the binding covers the whole header
+
+
+def test_struct_layouts_match_the_header():
+    assert C.sizeof(_ffi.rt_sphere) == 72 and C.sizeof(_ffi.rt_camera) == 152
+    assert C.sizeof(_ffi.rt_params) == 56 and _ffi.rt_params.t_min.offset == 24 and _ffi.rt_params.seed.offset == 32
+    assert rt.SPHERE_DTYPE.itemsize == 72
+    assert rt.SPHERE_DTYPE.fields["kind"][1] == _ffi.rt_sphere.kind.offset == 64
+
+
+def test_identity():
+    lib = _ffi.load()
+    assert lib.rt_backend_name() == b"hip-gfx950"
+    assert lib.rt_abi_version() == 1
+
+
+@pytest.mark.parametrize("kw,msg", [
+    (dict(width=1), "width and height"), (dict(height=1), "width and height"),
+    (dict(spp=-1), "spp"), (dict(t_min=0.0), "t_min"), (dict(tile_rows=0), "tile_rows"),
+    (dict(shard_index=2, shard_count=2), "shard_index"), (dict(shard_count=0), "shard_index"),
+    (dict(max_depth=-1), "max_depth"),
+])
+def test_parameter_validation(kw, msg):
+    base = dict(width=8, height=8, spp=1)
+    base.update(kw)
+    p = rt.make_params(base.pop("width"), base.pop("height"), base.pop("spp"), **base)
+    rows = C.c_int32()
+    rc = _ffi.load().rt_shard_rows(C.byref(p), C.byref(rows))
+    assert rc == -1 and msg in _ffi.load().rt_last_error().decode()
+
+
+def test_null_arguments_are_errors_not_crashes():
+    lib = _ffi.load()
+    assert lib.rt_shard_rows(None, None) == -1
+    assert lib.rt_create(0, None) == -1
+    assert lib.rt_destroy(None) == 0
+    assert lib.rt_upload_scene(None, None, 0) == -1
+
+
+def _gpu_present():
+    return os.path.exists("/dev/kfd")
+
+
+@pytest.mark.skipif(_gpu_present(), reason="this check is for machines without a GPU")
+def test_no_cpu_fallback_without_a_gpu():
+    """On a box with no HIP device the product must fail loudly, not fall back."""
+    with pytest.raises(rt.RtiowHipError) as e:
+        rt.Renderer(0)
+    assert "no HIP device" in str(e.value) or "fallback" in str(e.value)

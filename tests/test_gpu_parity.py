@@ -1,0 +1,168 @@
+"""GPU parity tests: librtiow_hip.so (through its C ABI) against the CPU oracle.
+
+Bar: BIT-EXACT.  The kernel computes every hit decision and every shading value
+in the reference's f64 arithmetic (f32 only filters the sphere scan,
+conservatively), and pixel sums are exact integers, so the u64 sums must equal
+Oracle B's on the same inputs, and the RGBA8 bytes must equal Oracle A's.
+The north_star's stated tolerance (per-pixel RMSE < 1e-4 vs CPU) is asserted
+against the literal Oracle A as well.
+"""
+import numpy as np
+import pytest
+
+import rtiow_amd as rt
+
+pytestmark = pytest.mark.gpu
+RMSE_GATE = 1e-4          # BASELINE.json north_star tolerance
+
+
+def both(renderer, oracle_mod, flat, w, h, spp, **kw):
+    renderer.upload_scene(flat)
+    cam = rt.book1_camera(w, h)
+    seed = kw.get("seed", 1)
+    max_depth = kw.get("max_depth", 50)
+    t_min = kw.get("t_min", 1e-4)
+    p = rt.make_params(w, h, spp, seed=seed, max_depth=max_depth, t_min=t_min, flags=kw.get("flags", 0))
+    sm, fix, st = renderer.render(cam, p)
+    op = oracle_mod.make_params(w, h, spp, seed=seed, max_depth=max_depth, t_min=t_min)
+    ocam = oracle_mod.camera_from_host(cam)
+    fb, sb, stb = oracle_mod.render_b(ocam, flat, op)
+    return (sm, fix, st), (fb, sb, stb), (ocam, op)
+
+
+def test_golden_fixture_bit_exact(renderer, book1_flat, golden_small):
+    renderer.upload_scene(book1_flat)
+    sm, fix, st = renderer.render(rt.book1_camera(32, 18), rt.make_params(32, 18, 4, seed=1))
+    assert np.array_equal(fix, golden_small["fix"])
+    assert np.array_equal(sm, golden_small["sum_f32"])
+    assert st["rays_traced"] == int(golden_small["rays_b"]) and st["samples"] == 32 * 18 * 4
+    assert np.array_equal(renderer.resolve_rgba8(fix, 4, flip=True), golden_small["rgba"])
+
+
+@pytest.mark.parametrize("w,h,spp,seed", [(64, 36, 4, 1), (400, 225, 10, 1), (200, 133, 7, 0xDEADBEEFCAFE)])
+def test_book1_bit_exact_vs_oracle_b(renderer, oracle_mod, book1_flat, w, h, spp, seed):
+    """(400,225,10) is BASELINE.json configs[0]; (200,133) is the reference's own 3:2 const size."""
+    (sm, fix, st), (fb, sb, stb), _ = both(renderer, oracle_mod, book1_flat, w, h, spp, seed=seed)
+    assert np.array_equal(fix, fb)
+    assert np.array_equal(sm, sb)
+    assert st["rays_traced"] == stb["rays_traced"]
+    assert st["samples"] == w * h * spp
+    assert st["sphere_tests"] == st["rays_traced"] * len(book1_flat)
+    assert np.array_equal(renderer.resolve_rgba8(fix, spp), oracle_mod.resolve_b(fb, spp))
+
+
+def test_rmse_vs_literal_oracle_a_and_identical_bytes(renderer, oracle_mod, book1_flat):
+    w, h, spp = 240, 135, 16
+    (sm, fix, st), _, (ocam, op) = both(renderer, oracle_mod, book1_flat, w, h, spp)
+    sa, sta = oracle_mod.render_a(ocam, book1_flat, op)
+    gpu_mean = fix.astype(np.float64) / 2.0 ** 32 / spp
+    rmse = float(np.sqrt(np.mean((gpu_mean - sa / spp) ** 2)))
+    assert rmse < 1e-9 < RMSE_GATE
+    assert st["rays_traced"] == sta["rays_traced"]
+    assert np.array_equal(renderer.resolve_rgba8(fix, spp), oracle_mod.resolve_a(sa, spp))
+
+
+def test_filter_never_changes_a_result(renderer, oracle_mod, book1_flat):
+    """RT_FLAG_NO_FILTER sends every sphere through the exact test: same bits, far more work."""
+    (sm, fix, st), (fb, _, _), _ = both(renderer, oracle_mod, book1_flat, 160, 90, 6)
+    (_, fix2, st2), _, _ = both(renderer, oracle_mod, book1_flat, 160, 90, 6, flags=rt.RT_FLAG_NO_FILTER)
+    assert np.array_equal(fix, fix2) and np.array_equal(fix, fb)
+    assert st2["candidates"] == st2["sphere_tests"] and st["candidates"] < st["sphere_tests"] // 50
+    assert st["exact_roots"] == st2["exact_roots"]
+
+
+def test_tenk_scene_bit_exact(renderer, oracle_mod):
+    """BASELINE.json configs[3]'s scene (10 001 spheres) at a size the oracle finishes in seconds."""
+    flat = rt.random_scene(1, grid=(-50, 49)).flatten()
+    (sm, fix, st), (fb, sb, stb), _ = both(renderer, oracle_mod, flat, 64, 36, 2)
+    assert np.array_equal(fix, fb) and st["rays_traced"] == stb["rays_traced"]
+    assert st["n_spheres"] == len(flat) == 10001
+
+
+@pytest.mark.parametrize("max_depth", [0, 1, 2, 5])
+def test_depth_limit(renderer, oracle_mod, book1_flat, max_depth):        # main.rs:40-42
+    (sm, fix, st), (fb, _, stb), _ = both(renderer, oracle_mod, book1_flat, 48, 27, 4, max_depth=max_depth)
+    assert np.array_equal(fix, fb) and st["rays_traced"] == stb["rays_traced"]
+    if max_depth == 0:
+        assert not fix.any() and st["rays_traced"] == 0
+
+
+def test_t_min_is_honoured(renderer, oracle_mod, book1_flat):             # main.rs:44
+    (sm, fix, st), (fb, _, _), _ = both(renderer, oracle_mod, book1_flat, 48, 27, 4, t_min=1e-2)
+    assert np.array_equal(fix, fb)
+
+
+def hand_scene(spheres):
+    w = rt.HittableList()
+    for s in spheres:
+        w.push(s)
+    return w.flatten()
+
+
+def test_empty_scene_is_pure_sky(renderer, oracle_mod):
+    flat = hand_scene([])
+    (sm, fix, st), (fb, _, _), _ = both(renderer, oracle_mod, flat, 40, 30, 3)
+    assert np.array_equal(fix, fb) and st["rays_traced"] == 40 * 30 * 3 and st["candidates"] == 0
+
+
+def test_tie_rule_and_material_kinds_on_a_hand_scene(renderer, oracle_mod):
+    """Coincident spheres (later wins, mod.rs:61-67), a hollow glass shell (negative radius flips
+    the normal through 1/radius, sphere.rs:37), fuzz 0 and 1 metals, a huge ground sphere."""
+    flat = hand_scene([
+        rt.Sphere(rt.Point3(0, -1000, 0), 1000, rt.Lambertian(rt.Color(0.5, 0.5, 0.5))),
+        rt.Sphere(rt.Point3(0, 1, 0), 1.0, rt.Lambertian(rt.Color(0.9, 0.1, 0.1))),
+        rt.Sphere(rt.Point3(0, 1, 0), 1.0, rt.Metal(rt.Color(0.8, 0.8, 0.8), 1.0)),      # same sphere, later
+        rt.Sphere(rt.Point3(4, 1, 0), 1.0, rt.Dialectric(1.5)),
+        rt.Sphere(rt.Point3(4, 1, 0), -0.9, rt.Dialectric(1.5)),
+        rt.Sphere(rt.Point3(-4, 1, 0), 1.0, rt.Metal(rt.Color(0.7, 0.6, 0.5), 0.0)),
+    ])
+    (sm, fix, st), (fb, _, stb), _ = both(renderer, oracle_mod, flat, 120, 68, 8)
+    assert np.array_equal(fix, fb) and st["rays_traced"] == stb["rays_traced"]
+
+
+def test_zero_spp_and_tiny_images(renderer, oracle_mod, book1_flat):
+    renderer.upload_scene(book1_flat)
+    sm, fix, st = renderer.render(rt.book1_camera(16, 9), rt.make_params(16, 9, 0))
+    assert not fix.any() and st["samples"] == 0
+    (sm, fix, st), (fb, _, _), _ = both(renderer, oracle_mod, book1_flat, 2, 2, 5)
+    assert np.array_equal(fix, fb)
+
+
+def test_resolve_flip_and_noflip(renderer, oracle_mod, book1_flat):       # main.rs:141-145
+    (sm, fix, st), (fb, _, _), _ = both(renderer, oracle_mod, book1_flat, 33, 21, 2)
+    a = renderer.resolve_rgba8(fix, 2, flip=False)
+    b = renderer.resolve_rgba8(fix, 2, flip=True)
+    assert np.array_equal(a[::-1], b) and (a[..., 3] == 255).all()
+    assert np.array_equal(a, oracle_mod.resolve_b(fb, 2, flip=False))
+
+
+def test_f64_divide_and_sqrt_are_correctly_rounded_on_device(renderer):
+    rng = np.random.default_rng(5)
+    a = np.abs(rng.standard_normal(1 << 18)) * 10.0 ** rng.integers(-30, 30, 1 << 18)
+    b = rng.standard_normal(1 << 18) * 10.0 ** rng.integers(-30, 30, 1 << 18)
+    a[:4] = [0.0, 1.0, 2.0, np.nextafter(1.0, 2.0)]
+    q, s = renderer.f64_div_sqrt(a, b)
+    assert np.array_equal(q, a / b) and np.array_equal(s, np.sqrt(a))
+
+
+def test_errors(renderer, book1_flat):
+    fresh = rt.Renderer(0)
+    try:
+        with pytest.raises(rt.RtiowHipError, match="rt_upload_scene has not been called"):
+            fresh.render(rt.book1_camera(8, 8), rt.make_params(8, 8, 1))
+        bad = book1_flat.copy()
+        bad["kind"][3] = 7
+        with pytest.raises(rt.RtiowHipError, match="unknown material kind"):
+            fresh.upload_scene(bad)
+        big = np.zeros(65536, dtype=rt.SPHERE_DTYPE)
+        big["radius"] = 1.0
+        with pytest.raises(rt.RtiowHipError, match="65535"):
+            fresh.upload_scene(big)
+        nan = book1_flat.copy()
+        nan["center"][2, 0] = np.inf
+        with pytest.raises(rt.RtiowHipError, match="finite"):
+            fresh.upload_scene(nan)
+    finally:
+        fresh.close()
+    with pytest.raises(rt.RtiowHipError, match="device_id"):
+        rt.Renderer(99)

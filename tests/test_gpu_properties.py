@@ -1,0 +1,128 @@
+"""Size-independent properties at BASELINE.json's full sizes (the oracle cannot
+finish these in seconds): determinism, sharding invariance, additive passes,
+work-decomposition invariance, sample accounting -- and the reference's own PNG
+sky rows reproduced by the GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import rtiow_amd as rt
+from rtiow_amd.distributed import shard_row_map
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cfg2(renderer, book1_flat):
+    """BASELINE.json configs[1]: book-1 final scene, 1200x675, 100 spp, depth 50."""
+    renderer.upload_scene(book1_flat)
+    w, h, spp = 1200, 675, 100
+    sm, fix, st = renderer.render(rt.book1_camera(w, h), rt.make_params(w, h, spp))
+    return w, h, spp, fix, st
+
+
+def test_cfg2_accounting(cfg2, book1_flat):
+    w, h, spp, fix, st = cfg2
+    assert st["samples"] == w * h * spp
+    assert 2.4 < st["rays_traced"] / st["samples"] < 2.9
+    assert st["sphere_tests"] == st["rays_traced"] * len(book1_flat)
+    mean = fix.astype(np.float64) / 2.0 ** 32 / spp
+    assert 0.0 <= mean.min() and mean.max() <= 1.0 + 1e-12          # sky <= 1 and albedos <= 1
+    assert 0.3 < mean.mean() < 0.6
+
+
+def test_cfg2_is_deterministic(renderer, book1_flat, cfg2):
+    w, h, spp, fix, st = cfg2
+    renderer.upload_scene(book1_flat)
+    _, again, st2 = renderer.render(rt.book1_camera(w, h), rt.make_params(w, h, spp))
+    assert np.array_equal(again, fix) and st2["rays_traced"] == st["rays_traced"]
+
+
+@pytest.mark.parametrize("count,tile", [(8, 8), (3, 16), (2, 1)])
+def test_cfg2_row_shards_reassemble_bit_identically(renderer, book1_flat, cfg2, count, tile):
+    """The 8-way row-tiled result must equal the 1-GPU result:
+    rendered here as `count` shards one after the other on one GPU."""
+    w, h, spp, fix, st = cfg2
+    renderer.upload_scene(book1_flat)
+    full = np.zeros_like(fix)
+    rays = 0
+    for k in range(count):
+        p = rt.make_params(w, h, spp, tile_rows=tile, shard_index=k, shard_count=count)
+        _, part, stk = renderer.render(rt.book1_camera(w, h), p)
+        rows = shard_row_map(h, tile, k, count)
+        assert part.shape[0] == len(rows)
+        full[rows] = part
+        rays += stk["rays_traced"]
+    assert np.array_equal(full, fix) and rays == st["rays_traced"]
+
+
+def test_cfg2_passes_are_additive(renderer, book1_flat, cfg2):
+    """spp split into passes with sample_begin; exact integer sums make it bit-identical."""
+    w, h, spp, fix, st = cfg2
+    renderer.upload_scene(book1_flat)
+    cam = rt.book1_camera(w, h)
+    acc = np.zeros_like(fix)
+    for begin, n in ((0, 37), (37, 1), (38, 62)):
+        _, part, _ = renderer.render(cam, rt.make_params(w, h, n, sample_begin=begin))
+        acc += part
+    assert np.array_equal(acc, fix)
+
+
+def test_cfg2_device_buffers_accumulate_flag(renderer, book1_flat, cfg2):
+    torch = pytest.importorskip("torch")
+    w, h, spp, fix, st = cfg2
+    renderer.upload_scene(book1_flat)
+    cam = rt.book1_camera(w, h)
+    d_fix = torch.zeros((h, w, 3), dtype=torch.int64, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    renderer.render_device(cam, rt.make_params(w, h, 60), d_fix.data_ptr(), stream)
+    renderer.render_device(cam, rt.make_params(w, h, 40, sample_begin=60, flags=rt.RT_FLAG_ACCUMULATE),
+                           d_fix.data_ptr(), stream)
+    d_sum = torch.empty((h, w, 3), dtype=torch.float32, device="cuda:0")
+    renderer.fix_to_f32_device(d_fix.data_ptr(), d_fix.numel(), d_sum.data_ptr(), stream)
+    d_rgba = torch.empty((h, w, 4), dtype=torch.uint8, device="cuda:0")
+    renderer.resolve_rgba8_device(d_fix.data_ptr(), w, h, spp, 1, d_rgba.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_fix.cpu().numpy().view(np.uint64), fix)
+    assert np.array_equal(d_rgba.cpu().numpy(), renderer.resolve_rgba8(fix, spp, flip=True))
+    want_sum = (fix.astype(np.float64) / 2.0 ** 32).astype(np.float32)
+    assert np.array_equal(d_sum.cpu().numpy(), want_sum)
+
+
+def test_work_decomposition_does_not_change_results(book1_flat, cfg2):
+    """Samples per work item and blocks per CU are scheduling knobs only."""
+    w, h, spp, fix, st = cfg2
+    for env in ({"RTIOW_CHUNK": "1"}, {"RTIOW_CHUNK": "7", "RTIOW_BLOCKS_PER_CU": "2"}, {"RTIOW_CHUNK": "100"}):
+        os.environ.update(env)
+        try:
+            r = rt.Renderer(0)
+            r.upload_scene(book1_flat)
+            _, got, st2 = r.render(rt.book1_camera(w, h), rt.make_params(w, h, spp))
+            r.close()
+        finally:
+            for k in env:
+                os.environ.pop(k)
+        assert np.array_equal(got, fix), env
+        assert st2["rays_traced"] == st["rays_traced"]
+
+
+def test_gpu_reproduces_the_reference_png_sky_rows(renderer, book1_flat):
+    """The GPU render at the reference PNG's geometry (1200x800, 3:2) gives the PNG's own
+    sky bytes: Camera, get_ray direction, sky gradient, to_rgba and the flip, end to end."""
+    fx = json.load(open(os.path.join(GOLDEN, "ref_png_sky_rows.json")))
+    w, h, spp = 1200, 800, 32
+    renderer.upload_scene(book1_flat)
+    cam = rt.Camera(rt.Point3(13, 2, 3), rt.Point3(0, 0, 0), rt.Vec3(0, 1, 0), 20.0, 3.0 / 2.0, 0.1, 10.0)
+    _, fix, _ = renderer.render(cam, rt.make_params(w, h, spp))
+    rgba = renderer.resolve_rgba8(fix, spp, flip=True)              # top row first, like the PNG
+    assert (rgba[..., 3] == 255).all()
+    for y in (0, 1, 4, 8, 24, 37, 50):
+        assert (rgba[y, :, :3] == np.array(fx["constant_rows"][str(y)], dtype=np.uint8)).all(), y
+    for pt in fx["points"]:
+        if pt["x"] != 600:
+            assert rgba[pt["y"], pt["x"], :3].tolist() == pt["rgb"]
+    m = rgba[..., :3].reshape(-1, 3).mean(0)                        # loose sanity band only
+    assert np.abs(m - np.array(fx["image_mean_rgb"])).max() < 15
