@@ -75,6 +75,14 @@ def load():
         raise RtiowHipError(
             f"{LIB_PATH} not found: build it with ./build_lib.sh (hipcc --offload-arch=gfx950); "
             "there is no CPU fallback for the render path")
+    # One process, one HIP runtime.  PyTorch ships its own libamdhip64.so.7 and the dynamic
+    # loader binds every later request for that SONAME to whichever copy came first; PyTorch
+    # only works on its own copy, this library works on either.  So when torch is installed
+    # it is imported first (device memory, streams and torch.distributed come from it anyway).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

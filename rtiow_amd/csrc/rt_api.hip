@@ -57,6 +57,7 @@ struct rt_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t own_stream = nullptr;
     bool launched = false;
+    unsigned long long zero_depth_samples = 0;
     rt_stats last{};
     // staging for the host-buffer entry points
     void *d_stage_fix = nullptr; size_t stage_fix_bytes = 0;
@@ -224,16 +225,16 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
         mat[6 * i + 1] = s.param;
         mat[6 * i + 2] = s.albedo[0]; mat[6 * i + 3] = s.albedo[1]; mat[6 * i + 4] = s.albedo[2];
         mat[6 * i + 5] = (double)s.kind;
-        // filter record: centre rounded to f32, radius^2 inflated by kappa (2 r^2 + |c|^2)
-        // and rounded UP (rt_device.hpp)
+        // filter record (rt_device.hpp): centre rounded to f32 and
+        // K' = |c|^2 (1-kappa) - r^2 (1+2 kappa), rounded DOWN (a smaller K' keeps more)
         const double c2 = s.center[0] * s.center[0] + s.center[1] * s.center[1] + s.center[2] * s.center[2];
-        const double r2f_exact = (r2 + kappa * (2.0 * r2 + c2)) * (1.0 + 1e-12);
-        float r2f = (float)r2f_exact;
-        if ((double)r2f < r2f_exact) r2f = std::nextafterf(r2f, INFINITY);
-        // spheres too small for f32's normal range are always sent to the exact test
-        if (!(r2 > 1e-30)) r2f = INFINITY;
+        const double kp_exact = c2 * (1.0 - kappa) - r2 * (1.0 + 2.0 * kappa);
+        float kp = (float)(kp_exact - std::fabs(kp_exact) * 1e-12);
+        if ((double)kp > kp_exact) kp = std::nextafterf(kp, -INFINITY);
+        // spheres outside f32's comfortable range always go to the exact test
+        if (!(r2 > 1e-30) || !(c2 + r2 < 1e30)) kp = -INFINITY;
         filt[4 * i + 0] = (float)s.center[0]; filt[4 * i + 1] = (float)s.center[1];
-        filt[4 * i + 2] = (float)s.center[2]; filt[4 * i + 3] = r2f;
+        filt[4 * i + 2] = (float)s.center[2]; filt[4 * i + 3] = kp;
     }
     RT_HIP(hipMalloc((void **)&ctx->d_filt, cnt * 4 * sizeof(float)));
     RT_HIP(hipMalloc((void **)&ctx->d_geo, cnt * 4 * sizeof(double)));
@@ -280,7 +281,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     const long long npix = (long long)rows * p->width;
     // samples per work item: small enough for a short tail, large enough that the
     // item count fits 31 bits
-    int chunk = ctx->chunk > 0 ? ctx->chunk : 8;
+    int chunk = ctx->chunk > 0 ? ctx->chunk : 2;
     if (chunk > p->spp) chunk = p->spp > 0 ? p->spp : 1;
     while (npix * (((long long)p->spp + chunk - 1) / chunk) > 0x7fffffffLL) chunk *= 2;
     const long long nchunks = p->spp > 0 ? ((long long)p->spp + chunk - 1) / chunk : 0;
@@ -305,15 +306,26 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     RT_HIP(hipMemsetAsync(ctx->d_queue, 0, 64, stream));
     RT_HIP(hipMemsetAsync(ctx->d_stats, 0, 64, stream));
 
+    memset(&ctx->last, 0, sizeof(ctx->last));
+    ctx->last.n_spheres = ctx->n_spheres;
+    ctx->last.block_threads = rt::kBlock;
+    ctx->zero_depth_samples = 0;
+    if (p->max_depth == 0 || kp.total_items == 0) {
+        // ray_color(depth <= 0) returns black without tracing (main.rs:40-42): the sums stay
+        // as they are and no ray is cast; nothing to launch.
+        RT_HIP(hipEventRecord(ctx->ev0, stream));
+        RT_HIP(hipEventRecord(ctx->ev1, stream));
+        ctx->zero_depth_samples = (unsigned long long)npix * (unsigned long long)p->spp;
+        ctx->launched = true;
+        return RT_OK;
+    }
+
     int grid = 0;
     if (p->flags & RT_FLAG_NO_FILTER) rc = launch_render<false>(ctx, kp, stream, &grid);
     else rc = launch_render<true>(ctx, kp, stream, &grid);
     if (rc) return rc;
     ctx->launched = true;
-    memset(&ctx->last, 0, sizeof(ctx->last));
-    ctx->last.n_spheres = ctx->n_spheres;
     ctx->last.grid_blocks = grid;
-    ctx->last.block_threads = rt::kBlock;
     return RT_OK;
 }
 
@@ -328,7 +340,7 @@ int rt_last_stats(rt_context *ctx, rt_stats *stats)
     unsigned long long h[4] = { 0, 0, 0, 0 };
     RT_HIP(hipMemcpy(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost));
     ctx->last.rays_traced = h[0];
-    ctx->last.samples = h[1];
+    ctx->last.samples = h[1] + ctx->zero_depth_samples;
     ctx->last.candidates = h[2];
     ctx->last.exact_roots = h[3];
     ctx->last.sphere_tests = h[0] * (unsigned long long)(ctx->last.n_spheres > 0 ? ctx->last.n_spheres : 0);

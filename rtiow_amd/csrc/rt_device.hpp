@@ -93,47 +93,55 @@ __device__ __forceinline__ unsigned long long quantize(double x)
 // ---- the f32 filter of the sphere scan ----------------
 //
 // For a ray (o, d) and a sphere (c, r) the reference rejects when
-//     disc = half_b^2 - a*cc < 0,  half_b = oc.d, a = d.d, cc = oc.oc - r^2  (sphere.rs:18-25).
-// The filter evaluates, in f32,
-//     D = half_b^2 + Bo - a' * (oc.oc - r2f)
-// with  a' = a(1 - KU),  Bo = KU a |o|^2,  r2f >= r^2 + kappa (2 r^2 + |c|^2),
-// kappa = KU/(1-KU), which in exact arithmetic equals
-//     disc + KU a (|oc|^2 + r^2 + |c|^2 + |o|^2).
-// The f32 evaluation of D is off from that by at most 28 u a (|oc|^2+r^2+|c|^2+|o|^2),
-// u = 2^-24 (error analysis in DESIGN.md), and KU = 64 u, so D < 0 implies
-// disc < 0: a sphere the filter drops is one the reference rejects.
-constexpr float kFilterKU = 64.0f * 5.9604644775390625e-08f;           // 2^-18
+//     disc = half_b^2 - a*cc < 0,  half_b = oc.d, a = d.d, cc = oc.oc - r^2  (sphere.rs:18-25),
+// whose sign does not depend on the length of d.  With g = d / sqrt(a (1 - KU)), so that
+// |g|^2 = 1/(1-KU), kappa = KU/(1-KU), and the per-sphere constant
+//     K' <= |c|^2 (1 - kappa) - r^2 (1 + 2 kappa)
+// the filter evaluates, in f32 with fused multiply-adds,
+//     hb  = o.g - c.g                                   (3 fma, o.g once per ray)
+//     D'' = hb^2 - ( |o|^2 (1 - kappa) - 2 o.c )        (3 fma + 1 fma)
+// and keeps the sphere iff D'' >= K'.  In exact arithmetic
+//     D'' - K' = disc/a + kappa ( (oc.d)^2/a + 2 r^2 + |c|^2 + |o|^2 )  >=  disc/a + kappa S,
+// S = |o|^2 + |c|^2 + r^2.  The f32 evaluation is off by at most 61 u S, u = 2^-24 (error
+// analysis in DESIGN.md section 5.2); kappa > KU = 128 u.  Hence disc >= 0 implies the
+// sphere is kept: a sphere the filter drops is one the reference rejects.
+constexpr float kFilterKU = 128.0f * 5.9604644775390625e-08f;           // 2^-17
 
 struct RayFilter {
-    float ox, oy, oz, dx, dy, dz;
-    float a_scaled;     // a' = a (1 - KU)
-    float bo;           // Bo = KU a |o|^2, or +inf when f32 cannot represent the ray safely
+    float gx, gy, gz;       // d / sqrt(a (1-KU))
+    float h0;               // o.g   (+inf: ray outside the analysed range -> keep everything)
+    float px, py, pz;       // -2 o
+    float o2;               // |o|^2 (1 - kappa)
 };
 
 __device__ __forceinline__ RayFilter make_filter(D3 o, D3 d)
 {
     RayFilter f;
-    f.ox = (float)o.x; f.oy = (float)o.y; f.oz = (float)o.z;
-    f.dx = (float)d.x; f.dy = (float)d.y; f.dz = (float)d.z;
-    const float a = __builtin_fmaf(f.dz, f.dz, __builtin_fmaf(f.dy, f.dy, f.dx * f.dx));
-    const float o2 = __builtin_fmaf(f.oz, f.oz, __builtin_fmaf(f.oy, f.oy, f.ox * f.ox));
-    f.a_scaled = a * (1.0f - kFilterKU);
-    f.bo = (kFilterKU * a) * o2;
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    const float a = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+    const float s = __builtin_amdgcn_rsqf(a * (1.0f - kFilterKU));          // v_rsq_f32, 1 ulp
+    f.gx = dx * s; f.gy = dy * s; f.gz = dz * s;
+    f.h0 = __builtin_fmaf(oz, f.gz, __builtin_fmaf(oy, f.gy, ox * f.gx));
+    f.px = -2.0f * ox; f.py = -2.0f * oy; f.pz = -2.0f * oz;
+    f.o2 = oo * (1.0f - kFilterKU / (1.0f - kFilterKU));
     // outside the range where the relative-error analysis holds: let everything through
-    const bool sane = (a > 1e-20f) && (a < 1e20f) && (o2 < 1e30f);
-    if (!sane) f.bo = __builtin_inff();
+    const bool sane = (a > 1e-20f) && (a < 1e20f) && (oo < 1e30f);
+    if (!sane) {
+        f.gx = f.gy = f.gz = 0.0f; f.px = f.py = f.pz = 0.0f; f.o2 = 0.0f;
+        f.h0 = __builtin_inff();                                            // hb = +inf, D'' = +inf
+    }
     return f;
 }
 
-// true: the sphere cannot be hit (disc < 0 is certain).  NaN compares false -> candidate.
-__device__ __forceinline__ bool filter_rejects(const RayFilter &f, float cx, float cy, float cz, float r2f)
+// true: the sphere is kept for the exact test.  (cx, cy, cz, kp) is its filter record.
+__device__ __forceinline__ bool filter_keeps(const RayFilter &f, float cx, float cy, float cz, float kp)
 {
-    const float ocx = f.ox - cx, ocy = f.oy - cy, ocz = f.oz - cz;
-    const float hb = __builtin_fmaf(ocz, f.dz, __builtin_fmaf(ocy, f.dy, ocx * f.dx));
-    const float cc = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -r2f)));
-    const float t = __builtin_fmaf(hb, hb, f.bo);
-    const float D = __builtin_fmaf(-f.a_scaled, cc, t);
-    return D < 0.0f;
+    const float hb = __builtin_fmaf(-cx, f.gx, __builtin_fmaf(-cy, f.gy, __builtin_fmaf(-cz, f.gz, f.h0)));
+    const float q = __builtin_fmaf(cx, f.px, __builtin_fmaf(cy, f.py, __builtin_fmaf(cz, f.pz, f.o2)));
+    const float D = __builtin_fmaf(hb, hb, -q);
+    return D >= kp;
 }
 
 } // namespace rt

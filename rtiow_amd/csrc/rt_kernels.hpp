@@ -13,7 +13,7 @@
 //   * the sphere scan (HittableList::hit, mod.rs:54-70) walks the list in
 //     order with a WAVE-UNIFORM index, so the 16-byte f32 filter records
 //     arrive through the scalar data path (s_load -> SGPRs) and cost no
-//     vector-memory or LDS bandwidth: 11 f32 VALU ops + 1 compare per test;
+//     vector-memory or LDS bandwidth: 7 f32 FMAs + 1 compare + 1 branch per test;
 //   * the scan itself decides nothing: it is a conservative f32 FILTER
 //     (rt_device.hpp).  Spheres it cannot rule out are appended to a short
 //     per-lane list in LDS and go through the reference's exact f64 test
@@ -43,7 +43,7 @@ struct KParams {
     int32_t chunk;             // samples per work item
     uint32_t npix;             // rows * width
     uint32_t total_items;      // npix * ceil(spp / chunk)
-    const float *filt;         // [n][4]  f32 filter record (cx, cy, cz, r2f)
+    const float *filt;         // [n][4]  f32 filter record (cx, cy, cz, K')
     const double *geo;         // [n][4]  exact (cx, cy, cz, r*r)
     const double *mat;         // [n][6]  exact (1/r, param, albedo rgb, kind)
     unsigned long long *fix;   // [rows][width][3] exact sums
@@ -196,21 +196,37 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
                     }
                     cnt = 0;
                 };
-                auto test = [&](int i) {
-                    const float __attribute__((address_space(4))) *q = filt + 4 * (size_t)i;
-                    if (!filter_rejects(f, q[0], q[1], q[2], q[3])) {
-                        cand[cnt][tid] = (uint16_t)i;
-                        cnt++;
+                // One filter test.  Candidates are rare per sphere (about one wave-test in ten
+                // has any), so the push sits behind a wave-level branch that is normally not taken.
+                auto test = [&](float cx, float cy, float cz, float kp, int i) {
+                    const bool keep = filter_keeps(f, cx, cy, cz, kp);
+                    if (__builtin_expect(__ballot(keep) != 0ull, 0)) {
+                        if (keep) {
+                            cand[cnt][tid] = (uint16_t)i;
+                            cnt++;
+                        }
                     }
                 };
-                const int nfull = n & ~(kScanUnroll - 1);
-                for (int i0 = 0; i0 < nfull; i0 += kScanUnroll) {
+                // The filter records stream through SGPRs in batches of kScanUnroll spheres
+                // (32 dwords, two s_load_dwordx16): one scalar-memory wait per ~100 VALU ops,
+                // hidden by the other waves of the SIMD.
+                constexpr int BW = 4 * kScanUnroll;
+                const int nb = n / kScanUnroll;
+                for (int bidx = 0; bidx < nb; ++bidx) {
+                    const float __attribute__((address_space(4))) *q = filt + (size_t)BW * (size_t)bidx;
+                    float rec[BW];
 #pragma unroll
-                    for (int k = 0; k < kScanUnroll; ++k) test(i0 + k);
+                    for (int k = 0; k < BW; ++k) rec[k] = q[k];
+#pragma unroll
+                    for (int k = 0; k < kScanUnroll; ++k)
+                        test(rec[4 * k + 0], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3], bidx * kScanUnroll + k);
                     // drain before any lane could overflow its list
                     if (__any(cnt > kCandCap - kScanUnroll)) drain();
                 }
-                for (int i = nfull; i < n; ++i) test(i);
+                for (int i = nb * kScanUnroll; i < n; ++i) {
+                    const float __attribute__((address_space(4))) *q = filt + 4 * (size_t)i;
+                    test(q[0], q[1], q[2], q[3], i);
+                }
                 drain();
             }
         }
