@@ -281,7 +281,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     const long long npix = (long long)rows * p->width;
     // samples per work item: small enough for a short tail, large enough that the
     // item count fits 31 bits
-    int chunk = ctx->chunk > 0 ? ctx->chunk : 2;
+    int chunk = ctx->chunk > 0 ? ctx->chunk : 4;
     if (chunk > p->spp) chunk = p->spp > 0 ? p->spp : 1;
     while (npix * (((long long)p->spp + chunk - 1) / chunk) > 0x7fffffffLL) chunk *= 2;
     const long long nchunks = p->spp > 0 ? ((long long)p->spp + chunk - 1) / chunk : 0;
