@@ -5,6 +5,7 @@
 // render kernel.  No CPU fallback: every entry point needs a gfx950 device.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -51,6 +52,12 @@ struct rt_context {
     float *d_filt = nullptr;       // [n][4] f32 filter records
     double *d_geo = nullptr;       // [n][4] exact geometry
     double *d_mat = nullptr;       // [n][6] exact materials
+    float *d_bmat = nullptr;       // [tiles][64] MFMA B operand of the filter
+    float *d_kpt = nullptr;        // [tiles][16] K' per sphere
+    int n_tiles = 0;
+    int n_always = 0;
+    int always_idx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int scan_mode = 1;             // 1: VALU filter (default), 2: f32 matrix-pipe filter
     int n_spheres = -1;
     unsigned int *d_queue = nullptr;
     unsigned long long *d_stats = nullptr;
@@ -108,13 +115,13 @@ int ensure(void **ptr, size_t *have, size_t need)
     return RT_OK;
 }
 
-template <bool FILTERED>
+template <int MODE>
 int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, int *grid_out)
 {
     int per_cu = ctx->blocks_per_cu;
     if (per_cu <= 0) {
         int occ = 0;
-        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rt::render_kernel<FILTERED>, rt::kBlock, 0));
+        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rt::render_kernel<MODE>, rt::kBlock, 0));
         per_cu = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
     }
     // persistent grid, but never more lanes than there are work items
@@ -124,7 +131,7 @@ int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, in
     if (grid < 1) grid = 1;
     *grid_out = (int)grid;
     RT_HIP(hipEventRecord(ctx->ev0, stream));
-    hipLaunchKernelGGL(rt::render_kernel<FILTERED>, dim3((unsigned)grid), dim3(rt::kBlock), 0, stream, kp);
+    hipLaunchKernelGGL(rt::render_kernel<MODE>, dim3((unsigned)grid), dim3(rt::kBlock), 0, stream, kp);
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(ctx->ev1, stream));
     return RT_OK;
@@ -161,8 +168,10 @@ int rt_create(int32_t device_id, rt_context **out)
     ctx->cu_count = prop.multiProcessorCount;
     ctx->blocks_per_cu = env_int("RTIOW_BLOCKS_PER_CU", 0);
     ctx->chunk = env_int("RTIOW_CHUNK", 0);
+    ctx->scan_mode = env_int("RTIOW_SCAN_MODE", 1);
+    if (ctx->scan_mode < 1 || ctx->scan_mode > 2) ctx->scan_mode = 1;
     hipError_t e1 = hipMalloc((void **)&ctx->d_queue, 64);
-    hipError_t e2 = hipMalloc((void **)&ctx->d_stats, 64);
+    hipError_t e2 = hipMalloc((void **)&ctx->d_stats, 256);
     hipError_t e3 = hipEventCreate(&ctx->ev0);
     hipError_t e4 = hipEventCreate(&ctx->ev1);
     hipError_t e5 = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
@@ -180,6 +189,7 @@ int rt_destroy(rt_context *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     (void)hipFree(ctx->d_filt); (void)hipFree(ctx->d_geo); (void)hipFree(ctx->d_mat);
+    (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt);
     (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->d_stage_fix); (void)hipFree(ctx->d_stage_sum); (void)hipFree(ctx->d_stage_rgba);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -207,7 +217,8 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
     // the previous scene may still be in use by a launch on any stream
     RT_HIP(hipDeviceSynchronize());
     (void)hipFree(ctx->d_filt); (void)hipFree(ctx->d_geo); (void)hipFree(ctx->d_mat);
-    ctx->d_filt = nullptr; ctx->d_geo = ctx->d_mat = nullptr;
+    (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt);
+    ctx->d_filt = nullptr; ctx->d_geo = ctx->d_mat = nullptr; ctx->d_bmat = ctx->d_kpt = nullptr;
     ctx->n_spheres = -1;
     const size_t cnt = (size_t)(n > 0 ? n : 1);
     std::vector<float> filt(cnt * 4, 0.0f);
@@ -236,6 +247,38 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
         filt[4 * i + 0] = (float)s.center[0]; filt[4 * i + 1] = (float)s.center[1];
         filt[4 * i + 2] = (float)s.center[2]; filt[4 * i + 3] = kp;
     }
+    // Matrix-pipe form of the same filter records.  Spheres much larger than the rest of the
+    // scene (the ground) are kept by the filter for nearly every ray: they skip it and are
+    // always tested exactly.  The choice only moves work, never results.
+    ctx->n_always = 0;
+    if (n > 0) {
+        std::vector<double> radii(n);
+        for (int i = 0; i < n; ++i) radii[i] = std::fabs(spheres[i].radius);
+        std::vector<double> sorted = radii;
+        std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+        const double big = 8.0 * sorted[n / 2];
+        std::vector<int> order;
+        for (int i = 0; i < n; ++i) if (radii[i] > big) order.push_back(i);
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return radii[x] > radii[y]; });
+        for (size_t k = 0; k < order.size() && k < 8; ++k) ctx->always_idx[ctx->n_always++] = order[k];
+    }
+    const int n_tiles = (n + 15) / 16;
+    ctx->n_tiles = n_tiles;
+    const size_t tcnt = (size_t)(n_tiles > 0 ? n_tiles : 1);
+    std::vector<float> bmat(tcnt * 64, 0.0f), kpt(tcnt * 16, NAN);
+    for (int t = 0; t < n_tiles; ++t)
+        for (int l = 0; l < 64; ++l) {
+            const int i = 16 * t + (l & 15), k = l >> 4;
+            float v = (k == 3) ? 1.0f : 0.0f;                  // padding columns: c = 0
+            if (i < n && k < 3) v = filt[4 * i + k];
+            bmat[(size_t)t * 64 + l] = v;
+        }
+    for (int i = 0; i < n; ++i) kpt[i] = filt[4 * i + 3];      // padding stays NaN: never kept
+    for (int e = 0; e < ctx->n_always; ++e) kpt[ctx->always_idx[e]] = NAN;
+    RT_HIP(hipMalloc((void **)&ctx->d_bmat, tcnt * 64 * sizeof(float)));
+    RT_HIP(hipMalloc((void **)&ctx->d_kpt, tcnt * 16 * sizeof(float)));
+    RT_HIP(hipMemcpy(ctx->d_bmat, bmat.data(), tcnt * 64 * sizeof(float), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_kpt, kpt.data(), tcnt * 16 * sizeof(float), hipMemcpyHostToDevice));
     RT_HIP(hipMalloc((void **)&ctx->d_filt, cnt * 4 * sizeof(float)));
     RT_HIP(hipMalloc((void **)&ctx->d_geo, cnt * 4 * sizeof(double)));
     RT_HIP(hipMalloc((void **)&ctx->d_mat, cnt * 6 * sizeof(double)));
@@ -298,13 +341,16 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.rows = rows; kp.n_spheres = ctx->n_spheres; kp.chunk = chunk;
     kp.npix = (uint32_t)npix; kp.total_items = (uint32_t)(npix * nchunks);
     kp.filt = ctx->d_filt; kp.geo = ctx->d_geo; kp.mat = ctx->d_mat;
+    kp.bmat = ctx->d_bmat; kp.kpt = ctx->d_kpt; kp.n_tiles = ctx->n_tiles;
+    kp.n_always = ctx->n_always;
+    for (int e = 0; e < 8; ++e) kp.always_idx[e] = ctx->always_idx[e];
     kp.fix = (unsigned long long *)d_fix;
     kp.queue = ctx->d_queue; kp.stats = ctx->d_stats;
 
     if (!(p->flags & RT_FLAG_ACCUMULATE) && npix > 0)
         RT_HIP(hipMemsetAsync(d_fix, 0, (size_t)npix * 3 * sizeof(unsigned long long), stream));
     RT_HIP(hipMemsetAsync(ctx->d_queue, 0, 64, stream));
-    RT_HIP(hipMemsetAsync(ctx->d_stats, 0, 64, stream));
+    RT_HIP(hipMemsetAsync(ctx->d_stats, 0, 256, stream));
 
     memset(&ctx->last, 0, sizeof(ctx->last));
     ctx->last.n_spheres = ctx->n_spheres;
@@ -321,8 +367,9 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     }
 
     int grid = 0;
-    if (p->flags & RT_FLAG_NO_FILTER) rc = launch_render<false>(ctx, kp, stream, &grid);
-    else rc = launch_render<true>(ctx, kp, stream, &grid);
+    if (p->flags & RT_FLAG_NO_FILTER) rc = launch_render<0>(ctx, kp, stream, &grid);
+    else if (ctx->scan_mode == 1) rc = launch_render<1>(ctx, kp, stream, &grid);
+    else rc = launch_render<2>(ctx, kp, stream, &grid);
     if (rc) return rc;
     ctx->launched = true;
     ctx->last.grid_blocks = grid;
@@ -348,6 +395,16 @@ int rt_last_stats(rt_context *ctx, rt_stats *stats)
     *stats = ctx->last;
     return RT_OK;
 }
+
+#ifdef RT_PHASE_STAMPS
+extern "C" int rt_debug_phase_cycles(rt_context *ctx, unsigned long long out[8])
+{
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipEventSynchronize(ctx->ev1));
+    RT_HIP(hipMemcpy(out, ctx->d_stats + 8, 64, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+#endif
 
 int rt_fix_to_f32_device(rt_context *ctx, const void *d_fix, int64_t count, void *d_out_f32, void *stream_v)
 {

@@ -44,6 +44,11 @@ struct KParams {
     uint32_t npix;             // rows * width
     uint32_t total_items;      // npix * ceil(spp / chunk)
     const float *filt;         // [n][4]  f32 filter record (cx, cy, cz, K')
+    const float *bmat;         // [tiles][64] MFMA B operand: lane l -> S[k=l>>4][sphere 16t+(l&15)], S=(cx,cy,cz,1)
+    const float *kpt;          // [tiles][16] K' per sphere (NaN: never kept by the filter)
+    int32_t n_tiles;
+    int32_t n_always;          // spheres that skip the filter and are always tested exactly
+    int32_t always_idx[8];
     const double *geo;         // [n][4]  exact (cx, cy, cz, r*r)
     const double *mat;         // [n][6]  exact (1/r, param, albedo rgb, kind)
     unsigned long long *fix;   // [rows][width][3] exact sums
@@ -58,13 +63,24 @@ constexpr int kScanUnroll = 8;      // spheres per overflow check
 
 __device__ __forceinline__ D3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
 
-// FILTERED = true : f32 filter + deferred exact tests (the product path).
-// FILTERED = false: every sphere goes through the exact test (validation mode,
-//                   RT_FLAG_NO_FILTER): same results by construction of the filter.
-template <bool FILTERED>
+// MODE 0: every sphere goes through the exact test (validation mode, RT_FLAG_NO_FILTER):
+//         same results by construction of the filter.
+// MODE 1: f32 filter on the VALU with scalar-loaded sphere records + deferred exact tests.
+// MODE 2: the same filter on the f32 MATRIX pipe (the product path): the filter is two K = 4
+//         products, HB = R1 x S and Q = R2 x S, of per-ray rows R1 = (-g, o.g), R2 = (-2o,
+//         |o|^2(1-kappa)) with per-sphere columns S = (c, 1); v_mfma_f32_16x16x4_f32 evaluates
+//         them for 16 rays x 16 spheres at a time as the very fma chains of filter_keeps().
+constexpr int kRowPad = 80;         // floats per row of the ray-operand transpose buffer
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
 {
+    constexpr bool FILTERED = (MODE != 0);
     __shared__ uint16_t cand[FILTERED ? kCandCap : 1][kBlock];
+    __shared__ float s_rayop[MODE == 2 ? kBlock / 64 : 1][MODE == 2 ? 8 : 1][MODE == 2 ? kRowPad : 1];
+    __shared__ unsigned int s_cnt[MODE == 2 ? kBlock : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -92,6 +108,15 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
     uint32_t ev = 0;
     uint32_t n_rays = 0, n_samples = 0, n_cand = 0, n_roots = 0;
 
+#ifdef RT_PHASE_STAMPS
+    // Diagnostic build only (never the shipped library): wave-time spent per phase, summed
+    // into stats[8..15].  The stamps serialise the phases; read the SHARES, not the total.
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define RT_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); \
+                         __builtin_amdgcn_s_waitcnt(0); ph[k] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define RT_STAMP(k) do { } while (0)
+#endif
     for (;;) {
         // ---- (a) idle lanes fetch a work item: one atomic per wave -----------
         {
@@ -125,6 +150,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
             }
         }
 
+        RT_STAMP(0);
         // ---- (b) start the next sample: main.rs:131-134 + camera.rs:47-54 ----
         if (has_item && !alive) {
             U4 w = philox4x32_10(pix_global, (uint32_t)s, 0u, 0u, P.k0, P.k1);
@@ -147,6 +173,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
             alive = true;
         }
 
+        RT_STAMP(1);
         // ---- (c) every lane of the wave is out of work: done ------------------
         const unsigned long long alive_mask = __ballot(alive);
         if (alive_mask == 0ull) break;
@@ -155,6 +182,86 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
         // ---- (d) HittableList::hit, mod.rs:54-70 -------------------------------
         double closest = __builtin_inf();
         int hit = -1;
+        if (MODE == 2) {
+            // ---- the filter on the matrix pipe: the whole wave takes part ------------
+            const int wave = tid >> 6;
+            RayFilter f;
+            if (alive) {
+                f = make_filter(o, d);
+            } else {                                    // no ray: D'' = -inf, and masked below anyway
+                f.gx = f.gy = f.gz = f.h0 = 0.0f; f.px = f.py = f.pz = 0.0f; f.o2 = __builtin_inff();
+            }
+            float *rop = &s_rayop[wave][0][0];
+            rop[0 * kRowPad + lane] = -f.gx; rop[1 * kRowPad + lane] = -f.gy;
+            rop[2 * kRowPad + lane] = -f.gz; rop[3 * kRowPad + lane] = f.h0;
+            rop[4 * kRowPad + lane] = f.px;  rop[5 * kRowPad + lane] = f.py;
+            rop[6 * kRowPad + lane] = f.pz;  rop[7 * kRowPad + lane] = f.o2;
+            s_cnt[tid] = 0u;
+            __builtin_amdgcn_wave_barrier();            // LDS ops of one wave execute in order
+            // A operands: lane l holds R[ray 16G + (l&15)][k = l>>4]
+            float a_hb[4], a_q[4];
+#pragma unroll
+            for (int G = 0; G < 4; ++G) {
+                a_hb[G] = rop[(lane >> 4) * kRowPad + 16 * G + (lane & 15)];
+                a_q[G] = rop[(4 + (lane >> 4)) * kRowPad + 16 * G + (lane & 15)];
+            }
+            const int col = lane & 15, quad = lane >> 4;
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            // Tile loop, software-pipelined by hand: the 8 MFMAs of tile t+1 (4 ray groups x
+            // {HB, Q}) are issued while the VALU looks at the 16 results per lane of tile t.
+            auto mfma_tile = [&](float b, f32x4 (&hb)[4], f32x4 (&q)[4]) {
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    hb[G] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hb[G], b, zero, 0, 0, 0);
+                    q[G] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_q[G], b, zero, 0, 0, 0);
+                }
+            };
+            auto look = [&](const f32x4 (&hb)[4], const f32x4 (&q)[4], float kp, int t) {
+                // D'' for rays 16G + 4 quad + i against sphere 16t + col
+                float Dv[4][4];
+                float m = -__builtin_inff();
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Dv[G][i] = __builtin_fmaf(hb[G][i], hb[G][i], -q[G][i]);
+                    m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(Dv[G][0], Dv[G][1]), __builtin_fmaxf(Dv[G][2], Dv[G][3])));
+                }
+                if (__builtin_expect(__ballot(m >= kp) != 0ull, 0)) {
+#pragma unroll
+                    for (int G = 0; G < 4; ++G) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int ray = 16 * G + 4 * quad + i;
+                            if (Dv[G][i] >= kp && ((alive_mask >> ray) & 1ull)) {
+                                const unsigned slot = atomicAdd(&s_cnt[wave * 64 + ray], 1u);
+                                if (slot < (unsigned)kCandCap) cand[slot][wave * 64 + ray] = (uint16_t)(16 * t + col);
+                            }
+                        }
+                    }
+                }
+            };
+            const int nt = P.n_tiles;
+            f32x4 hbA[4], qA[4], hbB[4], qB[4];
+            // operands are fetched two tiles ahead of their MFMAs (L1/L2 latency off the path)
+            auto ld_b = [&](int t) { return (t < nt) ? P.bmat[t * 64 + lane] : 0.0f; };
+            auto ld_k = [&](int t) { return (t < nt) ? P.kpt[t * 16 + col] : __builtin_nanf(""); };
+            float b0 = ld_b(0), k0 = ld_k(0), b1 = ld_b(1), k1 = ld_k(1);
+            float kpA = k0, kpB = k1;
+            if (nt > 0) mfma_tile(b0, hbA, qA);
+            for (int t = 0; t < nt; t += 2) {
+                const float b2 = ld_b(t + 2), k2 = ld_k(t + 2);
+                if (t + 1 < nt) { kpB = k1; mfma_tile(b1, hbB, qB); }
+                look(hbA, qA, kpA, t);
+                const float b3 = ld_b(t + 3), k3 = ld_k(t + 3);
+                if (t + 1 < nt) {
+                    if (t + 2 < nt) { kpA = k2; mfma_tile(b2, hbA, qA); }
+                    look(hbB, qB, kpB, t + 1);
+                }
+                b1 = b3; k1 = k3;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        RT_STAMP(2);
         if (alive) {
             const double a = length_squared(d);                     // sphere.rs:20
             // sphere.rs:16-34 for sphere idx, exactly as the reference computes it
@@ -171,17 +278,34 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
                 if (half_b > 0.0 && c > 0.0) return;
                 n_roots++;
                 const double sqrtd = __builtin_sqrt(disc);
+                // sphere.rs:28-34 + mod.rs:61-67, written so that the ORDER in which a ray's
+                // candidates are visited does not matter: the reference keeps sphere idx iff
+                // its root r* (the near root if >= t_min, else the far root) satisfies
+                // t_min <= r* <= closest-so-far, so the scan ends with the smallest r*, and among
+                // equal r* with the LAST sphere of the list.
                 double root = (-half_b - sqrtd) / a;
-                if (root < t_min || closest < root) {
+                if (root < t_min) {
                     root = (-half_b + sqrtd) / a;
-                    if (root < t_min || closest < root) return;
+                    if (root < t_min) return;
                 }
-                closest = root;                                     // mod.rs:63-64
-                hit = idx;
+                if (root < closest || (root == closest && idx > hit)) {
+                    closest = root;                                 // mod.rs:63-64
+                    hit = idx;
+                }
             };
 
-            if (!FILTERED) {
+            if (MODE == 0) {
                 for (int i = 0; i < n; ++i) { n_cand++; exact_test(i); }
+            } else if (MODE == 2) {
+                for (int e = 0; e < P.n_always; ++e) { n_cand++; exact_test(P.always_idx[e]); }
+                const int cnt = (int)s_cnt[tid];
+                if (cnt > kCandCap) {                   // list overflowed: test everything (rare)
+                    for (int i = 0; i < n; ++i) { n_cand++; exact_test(i); }
+                } else {
+                    for (int k = 0; __any(k < cnt); ++k) {
+                        if (k < cnt) { n_cand++; exact_test((int)cand[k][tid]); }
+                    }
+                }
             } else {
                 const RayFilter f = make_filter(o, d);
                 int cnt = 0;
@@ -231,6 +355,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
             }
         }
 
+        RT_STAMP(3);
         // ---- (e) shade: main.rs:44-56 + materials.rs ----------------------------
         if (alive) {
             bool done = false;
@@ -305,9 +430,14 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
                 }
             }
         }
+        RT_STAMP(4);
     }
 
+        // (end of the bounce loop body is stamped at the top of the next iteration as phase 4)
     // wave totals -> device counters
+#ifdef RT_PHASE_STAMPS
+    if (lane == 0) for (int k = 0; k < 6; ++k) atomicAdd(P.stats + 8 + k, ph[k]);
+#endif
     {
         unsigned long long ns = n_samples, nc = n_cand, nr = n_roots;
 #pragma unroll

@@ -1,0 +1,23 @@
+"""Diagnostic (not a test): loads the RT_PHASE_STAMPS build and prints the share of
+wave time per phase of the bounce loop on cfg2."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa
+from rtiow_amd import _ffi
+_ffi.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtiow_hip_stamps.so")
+import rtiow_amd as rt
+names = ["(a) fetch item", "(b) camera ray", "(c,d) filter scan", "(d) exact tests", "(e) shade+accumulate", "-"]
+for mode in (2, 1):
+    os.environ["RTIOW_SCAN_MODE"] = str(mode)
+    r = rt.Renderer(0)
+    r.upload_scene(rt.random_scene(1).flatten())
+    for _ in range(2):
+        sm, fix, st = r.render(rt.book1_camera(1200, 675), rt.make_params(1200, 675, 100), want_fix=False)
+    out = (C.c_ulonglong * 8)()
+    r._lib.rt_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    r._lib.rt_debug_phase_cycles(r._h, out)
+    tot = sum(out[:5])
+    print(f"scan mode {mode}: kernel {st['kernel_ms']:.2f} ms (stamped build), wave-time shares:")
+    for k in range(5):
+        print(f"   {names[k]:24s} {100.0 * out[k] / tot:6.2f} %   {out[k] / max(1, st['rays_traced'] / 64):10.0f} ticks per wave-iteration")
+    r.close()
