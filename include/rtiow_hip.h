@@ -176,6 +176,11 @@ int32_t rt_abi_version(void);
  * two operations whose correct rounding the bit-exact contract leans on). */
 int rt_f64_div_sqrt_device(rt_context *ctx, const double *a, const double *b, int32_t n,
                            double *out_div, double *out_sqrt);
+/* The two K = 4 products of the scan filter exactly as the render
+ * kernel's matrix-pipe tiles evaluate them: r1, r2: [64][4] ray rows, s: [16][4] sphere
+ * columns, out_hb, out_q: [64][16].  bf16x3 != 0 selects the three-piece bf16 form. */
+int rt_filter_products_device(rt_context *ctx, const float *r1, const float *r2, const float *s,
+                               int32_t bf16x3, float *out_hb, float *out_q);
 int rt_philox_device(rt_context *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 #ifdef __cplusplus

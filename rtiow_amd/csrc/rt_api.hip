@@ -54,10 +54,12 @@ struct rt_context {
     double *d_mat = nullptr;       // [n][6] exact materials
     float *d_bmat = nullptr;       // [tiles][64] MFMA B operand of the filter
     float *d_kpt = nullptr;        // [tiles][16] K' per sphere
+    uint4 *d_bmat16 = nullptr;     // [tiles][64] bf16x3 B operand
+    float *d_kpt16 = nullptr;      // [tiles][16] K' for the bf16x3 form
     int n_tiles = 0;
     int n_always = 0;
     int always_idx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int scan_mode = 1;             // 1: VALU filter (default), 2: f32 matrix-pipe filter
+    int scan_mode = 3;             // filter: 1 VALU + scalar loads, 2 f32 MFMA, 3 bf16x3 MFMA (default)
     int n_spheres = -1;
     unsigned int *d_queue = nullptr;
     unsigned long long *d_stats = nullptr;
@@ -168,8 +170,8 @@ int rt_create(int32_t device_id, rt_context **out)
     ctx->cu_count = prop.multiProcessorCount;
     ctx->blocks_per_cu = env_int("RTIOW_BLOCKS_PER_CU", 0);
     ctx->chunk = env_int("RTIOW_CHUNK", 0);
-    ctx->scan_mode = env_int("RTIOW_SCAN_MODE", 1);
-    if (ctx->scan_mode < 1 || ctx->scan_mode > 2) ctx->scan_mode = 1;
+    ctx->scan_mode = env_int("RTIOW_SCAN_MODE", 3);
+    if (ctx->scan_mode < 1 || ctx->scan_mode > 3) ctx->scan_mode = 3;
     hipError_t e1 = hipMalloc((void **)&ctx->d_queue, 64);
     hipError_t e2 = hipMalloc((void **)&ctx->d_stats, 256);
     hipError_t e3 = hipEventCreate(&ctx->ev0);
@@ -189,7 +191,7 @@ int rt_destroy(rt_context *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     (void)hipFree(ctx->d_filt); (void)hipFree(ctx->d_geo); (void)hipFree(ctx->d_mat);
-    (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt);
+    (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt); (void)hipFree(ctx->d_bmat16); (void)hipFree(ctx->d_kpt16);
     (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->d_stage_fix); (void)hipFree(ctx->d_stage_sum); (void)hipFree(ctx->d_stage_rgba);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -217,8 +219,9 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
     // the previous scene may still be in use by a launch on any stream
     RT_HIP(hipDeviceSynchronize());
     (void)hipFree(ctx->d_filt); (void)hipFree(ctx->d_geo); (void)hipFree(ctx->d_mat);
-    (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt);
+    (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt); (void)hipFree(ctx->d_bmat16); (void)hipFree(ctx->d_kpt16);
     ctx->d_filt = nullptr; ctx->d_geo = ctx->d_mat = nullptr; ctx->d_bmat = ctx->d_kpt = nullptr;
+    ctx->d_bmat16 = nullptr; ctx->d_kpt16 = nullptr;
     ctx->n_spheres = -1;
     const size_t cnt = (size_t)(n > 0 ? n : 1);
     std::vector<float> filt(cnt * 4, 0.0f);
@@ -262,11 +265,13 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
         std::sort(order.begin(), order.end(), [&](int x, int y) { return radii[x] > radii[y]; });
         for (size_t k = 0; k < order.size() && k < 8; ++k) ctx->always_idx[ctx->n_always++] = order[k];
     }
-    const int n_tiles = (n + 15) / 16;
+    // tile count rounded up to even, plus two spare tiles so the pipelined loop never
+    // branches on a table bound (padding columns carry K' = NaN: never kept)
+    const int n_tiles = 2 * ((n + 31) / 32);
     ctx->n_tiles = n_tiles;
-    const size_t tcnt = (size_t)(n_tiles > 0 ? n_tiles : 1);
+    const size_t tcnt = (size_t)n_tiles + 2;
     std::vector<float> bmat(tcnt * 64, 0.0f), kpt(tcnt * 16, NAN);
-    for (int t = 0; t < n_tiles; ++t)
+    for (int t = 0; t < n_tiles + 2; ++t)
         for (int l = 0; l < 64; ++l) {
             const int i = 16 * t + (l & 15), k = l >> 4;
             float v = (k == 3) ? 1.0f : 0.0f;                  // padding columns: c = 0
@@ -275,6 +280,44 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
         }
     for (int i = 0; i < n; ++i) kpt[i] = filt[4 * i + 3];      // padding stays NaN: never kept
     for (int e = 0; e < ctx->n_always; ++e) kpt[ctx->always_idx[e]] = NAN;
+    // bf16x3 form: each S value as three bf16 pieces in the element order the A side pairs
+    // with (rt_device.hpp, a_operand_bf16x3), and K' recomputed with that scheme's larger KU
+    auto bf16_rne = [](float x) -> uint32_t {
+        uint32_t u; memcpy(&u, &x, 4);
+        return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+    };
+    auto bf16_to_f32 = [](uint32_t b) -> float { uint32_t u = b << 16; float x; memcpy(&x, &u, 4); return x; };
+    std::vector<uint4> bmat16(tcnt * 64, make_uint4(0u, 0u, 0u, 0u));
+    std::vector<float> kpt16(tcnt * 16, NAN);
+    for (size_t e = 0; e < bmat.size(); ++e) {
+        const float y = bmat[e];
+        const uint32_t y1 = bf16_rne(y);
+        const float r1 = y - bf16_to_f32(y1);
+        const uint32_t y2 = bf16_rne(r1);
+        const float r2 = r1 - bf16_to_f32(y2);
+        const uint32_t y3 = bf16_rne(r2);
+        bmat16[e] = make_uint4(y1 | (y2 << 16), y1 | (y3 << 16), y2 | (y1 << 16), y3 | (y2 << 16));
+    }
+    {
+        const double KU3 = (double)rt::kFilterKU_bf16x3, kappa3 = KU3 / (1.0 - KU3);
+        for (int i = 0; i < n; ++i) {
+            const rt_sphere &sp = spheres[i];
+            const double r2 = sp.radius * sp.radius;
+            const double cf[3] = { (double)filt[4 * i], (double)filt[4 * i + 1], (double)filt[4 * i + 2] };
+            (void)cf;
+            const double c2 = sp.center[0] * sp.center[0] + sp.center[1] * sp.center[1] + sp.center[2] * sp.center[2];
+            const double kp_exact = c2 * (1.0 - kappa3) - r2 * (1.0 + 2.0 * kappa3);
+            float kpv = (float)(kp_exact - std::fabs(kp_exact) * 1e-12);
+            if ((double)kpv > kp_exact) kpv = std::nextafterf(kpv, -INFINITY);
+            if (!(r2 > 1e-30) || !(c2 + r2 < 1e30)) kpv = -INFINITY;
+            kpt16[i] = kpv;
+        }
+        for (int e = 0; e < ctx->n_always; ++e) kpt16[ctx->always_idx[e]] = NAN;
+    }
+    RT_HIP(hipMalloc((void **)&ctx->d_bmat16, tcnt * 64 * sizeof(uint4)));
+    RT_HIP(hipMalloc((void **)&ctx->d_kpt16, tcnt * 16 * sizeof(float)));
+    RT_HIP(hipMemcpy(ctx->d_bmat16, bmat16.data(), tcnt * 64 * sizeof(uint4), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_kpt16, kpt16.data(), tcnt * 16 * sizeof(float), hipMemcpyHostToDevice));
     RT_HIP(hipMalloc((void **)&ctx->d_bmat, tcnt * 64 * sizeof(float)));
     RT_HIP(hipMalloc((void **)&ctx->d_kpt, tcnt * 16 * sizeof(float)));
     RT_HIP(hipMemcpy(ctx->d_bmat, bmat.data(), tcnt * 64 * sizeof(float), hipMemcpyHostToDevice));
@@ -342,6 +385,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.npix = (uint32_t)npix; kp.total_items = (uint32_t)(npix * nchunks);
     kp.filt = ctx->d_filt; kp.geo = ctx->d_geo; kp.mat = ctx->d_mat;
     kp.bmat = ctx->d_bmat; kp.kpt = ctx->d_kpt; kp.n_tiles = ctx->n_tiles;
+    kp.bmat16 = ctx->d_bmat16; kp.kpt16 = ctx->d_kpt16;
     kp.n_always = ctx->n_always;
     for (int e = 0; e < 8; ++e) kp.always_idx[e] = ctx->always_idx[e];
     kp.fix = (unsigned long long *)d_fix;
@@ -369,7 +413,8 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     int grid = 0;
     if (p->flags & RT_FLAG_NO_FILTER) rc = launch_render<0>(ctx, kp, stream, &grid);
     else if (ctx->scan_mode == 1) rc = launch_render<1>(ctx, kp, stream, &grid);
-    else rc = launch_render<2>(ctx, kp, stream, &grid);
+    else if (ctx->scan_mode == 2) rc = launch_render<2>(ctx, kp, stream, &grid);
+    else rc = launch_render<3>(ctx, kp, stream, &grid);
     if (rc) return rc;
     ctx->launched = true;
     ctx->last.grid_blocks = grid;
@@ -506,6 +551,28 @@ int rt_f64_div_sqrt_device(rt_context *ctx, const double *a, const double *b, in
     RT_HIP(hipGetLastError());
     RT_HIP(hipMemcpyAsync(out_div, dq, bytes, hipMemcpyDeviceToHost, ctx->own_stream));
     RT_HIP(hipMemcpyAsync(out_sqrt, dr, bytes, hipMemcpyDeviceToHost, ctx->own_stream));
+    RT_HIP(hipStreamSynchronize(ctx->own_stream));
+    return RT_OK;
+}
+
+int rt_filter_products_device(rt_context *ctx, const float *r1, const float *r2, const float *s,
+                               int32_t bf16x3, float *out_hb, float *out_q)
+{
+    if (!ctx || !r1 || !r2 || !s || !out_hb || !out_q) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    RT_HIP(hipSetDevice(ctx->device));
+    const size_t in_f = 64 * 4 * 2 + 16 * 4, out_f = 64 * 16 * 2;
+    int rc = ensure(&ctx->d_stage_fix, &ctx->stage_fix_bytes, (in_f + out_f) * sizeof(float));
+    if (rc) return rc;
+    float *d = (float *)ctx->d_stage_fix;
+    float *d_r1 = d, *d_r2 = d + 256, *d_s = d + 512, *d_hb = d + 576, *d_q = d + 576 + 1024;
+    RT_HIP(hipMemcpyAsync(d_r1, r1, 256 * 4, hipMemcpyHostToDevice, ctx->own_stream));
+    RT_HIP(hipMemcpyAsync(d_r2, r2, 256 * 4, hipMemcpyHostToDevice, ctx->own_stream));
+    RT_HIP(hipMemcpyAsync(d_s, s, 64 * 4, hipMemcpyHostToDevice, ctx->own_stream));
+    hipLaunchKernelGGL(rt::filter_products_kernel, dim3(1), dim3(64), 0, ctx->own_stream,
+                       (const float *)d_r1, (const float *)d_r2, (const float *)d_s, (int)bf16x3, d_hb, d_q);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemcpyAsync(out_hb, d_hb, 1024 * 4, hipMemcpyDeviceToHost, ctx->own_stream));
+    RT_HIP(hipMemcpyAsync(out_q, d_q, 1024 * 4, hipMemcpyDeviceToHost, ctx->own_stream));
     RT_HIP(hipStreamSynchronize(ctx->own_stream));
     return RT_OK;
 }

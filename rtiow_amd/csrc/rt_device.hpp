@@ -105,32 +105,39 @@ __device__ __forceinline__ unsigned long long quantize(double x)
 // S = |o|^2 + |c|^2 + r^2.  The f32 evaluation is off by at most 61 u S, u = 2^-24 (error
 // analysis in DESIGN.md section 5.2); kappa > KU = 128 u.  Hence disc >= 0 implies the
 // sphere is kept: a sphere the filter drops is one the reference rejects.
-constexpr float kFilterKU = 128.0f * 5.9604644775390625e-08f;           // 2^-17
+// KU per evaluation scheme: 128 u for the f32 fma chains (VALU, f32 MFMA); 1024 u for the
+// bf16x3 matrix form, whose 32-term accumulation is bounded by 472 u S.
+constexpr float kUnitRoundoff = 5.9604644775390625e-08f;                // 2^-24
+constexpr float kFilterKU = 128.0f * kUnitRoundoff;                     // 2^-17
+constexpr float kFilterKU_bf16x3 = 1024.0f * kUnitRoundoff;             // 2^-14
 
 struct RayFilter {
     float gx, gy, gz;       // d / sqrt(a (1-KU))
     float h0;               // o.g   (+inf: ray outside the analysed range -> keep everything)
     float px, py, pz;       // -2 o
     float o2;               // |o|^2 (1 - kappa)
+    bool sane;              // false: outside the analysed range, every sphere must be kept
 };
 
+template <bool BF16X3 = false>
 __device__ __forceinline__ RayFilter make_filter(D3 o, D3 d)
 {
+    constexpr float KU = BF16X3 ? kFilterKU_bf16x3 : kFilterKU;
     RayFilter f;
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
     const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
     const float a = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
     const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
-    const float s = __builtin_amdgcn_rsqf(a * (1.0f - kFilterKU));          // v_rsq_f32, 1 ulp
+    const float s = __builtin_amdgcn_rsqf(a * (1.0f - KU));                 // v_rsq_f32, 1 ulp
     f.gx = dx * s; f.gy = dy * s; f.gz = dz * s;
     f.h0 = __builtin_fmaf(oz, f.gz, __builtin_fmaf(oy, f.gy, ox * f.gx));
     f.px = -2.0f * ox; f.py = -2.0f * oy; f.pz = -2.0f * oz;
-    f.o2 = oo * (1.0f - kFilterKU / (1.0f - kFilterKU));
+    f.o2 = oo * (1.0f - KU / (1.0f - KU));
     // outside the range where the relative-error analysis holds: let everything through
-    const bool sane = (a > 1e-20f) && (a < 1e20f) && (oo < 1e30f);
-    if (!sane) {
+    f.sane = (a > 1e-20f) && (a < 1e20f) && (oo < 1e30f);
+    if (!f.sane) {
         f.gx = f.gy = f.gz = 0.0f; f.px = f.py = f.pz = 0.0f; f.o2 = 0.0f;
-        f.h0 = __builtin_inff();                                            // hb = +inf, D'' = +inf
+        f.h0 = BF16X3 ? 0.0f : __builtin_inff();                            // f32 forms: D'' = +inf
     }
     return f;
 }
@@ -142,6 +149,41 @@ __device__ __forceinline__ bool filter_keeps(const RayFilter &f, float cx, float
     const float q = __builtin_fmaf(cx, f.px, __builtin_fmaf(cy, f.py, __builtin_fmaf(cz, f.pz, f.o2)));
     const float D = __builtin_fmaf(hb, hb, -q);
     return D >= kp;
+}
+
+// ---- bf16x3: an f32 value as the exact sum of three bf16 pieces ------------------------
+// x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = x - x1 - x2 (8 significant bits
+// each, round to nearest even; the remainders are exact in f32).  A product x*y then is the
+// sum of nine exact bf16 x bf16 products; the matrix form keeps the eight of relative size
+// >= 2^-24 and drops x3*y3 (<= 2^-32).
+__device__ __forceinline__ uint32_t bf16_rne_bits(float x)
+{
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+struct Bf3 { uint32_t p1, p2, p3; };    // bf16 bit patterns in the low 16 bits
+__device__ __forceinline__ Bf3 split_bf16x3(float x)
+{
+    Bf3 r;
+    r.p1 = bf16_rne_bits(x);
+    const float r1 = x - __uint_as_float(r.p1 << 16);
+    r.p2 = bf16_rne_bits(r1);
+    const float r2 = r1 - __uint_as_float(r.p2 << 16);
+    r.p3 = bf16_rne_bits(r2);
+    return r;
+}
+// A-side element order (x1,x1,x2,x1,x2,x3,x2,x3) against the B-side order
+// (y1,y2,y1,y3,y2,y1,y3,y2) built on the host: the 8 products listed above.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 a_operand_bf16x3(float x)
+{
+    const Bf3 s = split_bf16x3(x);
+    uint4 w;
+    w.x = s.p1 | (s.p1 << 16);      // x1, x1
+    w.y = s.p2 | (s.p1 << 16);      // x2, x1
+    w.z = s.p2 | (s.p3 << 16);      // x2, x3
+    w.w = s.p2 | (s.p3 << 16);      // x2, x3
+    return __builtin_bit_cast(bf16x8, w);
 }
 
 } // namespace rt

@@ -46,6 +46,8 @@ struct KParams {
     const float *filt;         // [n][4]  f32 filter record (cx, cy, cz, K')
     const float *bmat;         // [tiles][64] MFMA B operand: lane l -> S[k=l>>4][sphere 16t+(l&15)], S=(cx,cy,cz,1)
     const float *kpt;          // [tiles][16] K' per sphere (NaN: never kept by the filter)
+    const uint4 *bmat16;       // [tiles][64] bf16x3 B operand: 8 bf16 (y1,y2,y1,y3,y2,y1,y3,y2) of S[k][sphere]
+    const float *kpt16;        // [tiles][16] K' for the bf16x3 form (larger KU)
     int32_t n_tiles;
     int32_t n_always;          // spheres that skip the filter and are always tested exactly
     int32_t always_idx[8];
@@ -60,16 +62,20 @@ constexpr int RT_KIND_LAMBERTIAN = 0, RT_KIND_METAL = 1, RT_KIND_DIALECTRIC = 2;
 constexpr int kBlock = 256;
 constexpr int kCandCap = 24;        // per-lane candidate slots
 constexpr int kScanUnroll = 8;      // spheres per overflow check
+constexpr int kItemBlock = 128;     // work items a wave reserves per atomic (>= 64)
 
 __device__ __forceinline__ D3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
 
 // MODE 0: every sphere goes through the exact test (validation mode, RT_FLAG_NO_FILTER):
 //         same results by construction of the filter.
 // MODE 1: f32 filter on the VALU with scalar-loaded sphere records + deferred exact tests.
-// MODE 2: the same filter on the f32 MATRIX pipe (the product path): the filter is two K = 4
-//         products, HB = R1 x S and Q = R2 x S, of per-ray rows R1 = (-g, o.g), R2 = (-2o,
-//         |o|^2(1-kappa)) with per-sphere columns S = (c, 1); v_mfma_f32_16x16x4_f32 evaluates
-//         them for 16 rays x 16 spheres at a time as the very fma chains of filter_keeps().
+// MODE 2: the same filter on the f32 MATRIX pipe: the filter is two K = 4 products,
+//         HB = R1 x S and Q = R2 x S, of per-ray rows R1 = (-g, o.g), R2 = (-2o, |o|^2(1-kappa))
+//         with per-sphere columns S = (c, 1); v_mfma_f32_16x16x4_f32 evaluates them for
+//         16 rays x 16 spheres at a time as the very fma chains of filter_keeps().
+// MODE 3: the same two products on the bf16 matrix pipe (16x the f32 rate): every f32 operand
+//         is the exact sum of three bf16 pieces, and one v_mfma_f32_16x16x32_bf16 adds up the
+//         8 significant piece products of each of the 4 components (K = 32).
 constexpr int kRowPad = 80;         // floats per row of the ray-operand transpose buffer
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -79,8 +85,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
 {
     constexpr bool FILTERED = (MODE != 0);
     __shared__ uint16_t cand[FILTERED ? kCandCap : 1][kBlock];
-    __shared__ float s_rayop[MODE == 2 ? kBlock / 64 : 1][MODE == 2 ? 8 : 1][MODE == 2 ? kRowPad : 1];
-    __shared__ unsigned int s_cnt[MODE == 2 ? kBlock : 1];
+    constexpr bool MATRIX = (MODE == 2 || MODE == 3);
+    __shared__ float s_rayop[MATRIX ? kBlock / 64 : 1][MATRIX ? 8 : 1][MATRIX ? kRowPad : 1];
+    __shared__ unsigned int s_cnt[MATRIX ? kBlock : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -107,6 +114,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
     int depth = 0;
     uint32_t ev = 0;
     uint32_t n_rays = 0, n_samples = 0, n_cand = 0, n_roots = 0;
+    uint32_t wave_next = 0, wave_end = 0;          // this wave's reserved block of work items (uniform)
 
 #ifdef RT_PHASE_STAMPS
     // Diagnostic build only (never the shipped library): wave-time spent per phase, summed
@@ -118,26 +126,34 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
 #define RT_STAMP(k) do { } while (0)
 #endif
     for (;;) {
-        // ---- (a) idle lanes fetch a work item: one atomic per wave -----------
+        // ---- (a) idle lanes take work items ------------------------------------
+        // A wave reserves kItemBlock consecutive items with ONE returning atomic on the
+        // device-wide counter and deals them to its lanes (ballot -> popcount -> prefix rank)
+        // until the block is used up: one word sustains only ~88 dequeues/us chip-wide
+        // (MI355X_MICROARCH.md, row "dequeue"), and a fetch per wave per bounce hit that wall.
         {
             const bool want = !has_item && !dead;
             const unsigned long long m = __ballot(want);
             if (m != 0ull) {
                 const uint32_t cnt = (uint32_t)__popcll(m);
-                const int leader = (int)__builtin_ctzll(m);
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(P.queue, cnt);
-                base = __shfl(base, leader);
+                const uint32_t avail = wave_end - wave_next;
+                uint32_t newbase = 0;
+                if (cnt > avail) {                                  // wave-uniform
+                    const int leader = (int)__builtin_ctzll(m);
+                    if (lane == leader) newbase = atomicAdd(P.queue, (unsigned)kItemBlock);
+                    newbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(newbase, leader));
+                }
                 if (want) {
-                    const uint32_t w = base + (uint32_t)__popcll(m & lane_lt);
+                    const uint32_t r = (uint32_t)__popcll(m & lane_lt);
+                    const uint32_t w = (r < avail) ? wave_next + r : newbase + (r - avail);
                     if (w < P.total_items) {
                         const uint32_t c = w / P.npix;
                         pix_local = w - c * P.npix;
-                        const uint32_t r = pix_local / (uint32_t)P.width;
-                        const uint32_t i = pix_local - r * (uint32_t)P.width;
-                        const uint32_t lt = r / (uint32_t)P.tile_rows;             // local tile
+                        const uint32_t rr = pix_local / (uint32_t)P.width;
+                        const uint32_t i = pix_local - rr * (uint32_t)P.width;
+                        const uint32_t lt = rr / (uint32_t)P.tile_rows;            // local tile
                         const uint32_t j = (lt * (uint32_t)P.shard_count + (uint32_t)P.shard_index) * (uint32_t)P.tile_rows
-                                           + (r - lt * (uint32_t)P.tile_rows);
+                                           + (rr - lt * (uint32_t)P.tile_rows);
                         pix_global = j * (uint32_t)P.width + i;
                         fi = (double)i; fj = (double)j;
                         s = P.sample_begin + (int)c * P.chunk;
@@ -147,6 +163,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
                         dead = true;
                     }
                 }
+                if (cnt > avail) { wave_next = newbase + (cnt - avail); wave_end = newbase + (uint32_t)kItemBlock; }
+                else wave_next += cnt;
             }
         }
 
@@ -182,14 +200,14 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
         // ---- (d) HittableList::hit, mod.rs:54-70 -------------------------------
         double closest = __builtin_inf();
         int hit = -1;
-        if (MODE == 2) {
+        if (MATRIX) {
             // ---- the filter on the matrix pipe: the whole wave takes part ------------
             const int wave = tid >> 6;
             RayFilter f;
             if (alive) {
-                f = make_filter(o, d);
-            } else {                                    // no ray: D'' = -inf, and masked below anyway
-                f.gx = f.gy = f.gz = f.h0 = 0.0f; f.px = f.py = f.pz = 0.0f; f.o2 = __builtin_inff();
+                f = make_filter<MODE == 3>(o, d);
+            } else {                                    // no ray: D'' hugely negative, never kept
+                f.gx = f.gy = f.gz = f.h0 = 0.0f; f.px = f.py = f.pz = 0.0f; f.o2 = 1e30f; f.sane = true;
             }
             float *rop = &s_rayop[wave][0][0];
             rop[0 * kRowPad + lane] = -f.gx; rop[1 * kRowPad + lane] = -f.gy;
@@ -207,59 +225,87 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
             }
             const int col = lane & 15, quad = lane >> 4;
             const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-            // Tile loop, software-pipelined by hand: the 8 MFMAs of tile t+1 (4 ray groups x
-            // {HB, Q}) are issued while the VALU looks at the 16 results per lane of tile t.
-            auto mfma_tile = [&](float b, f32x4 (&hb)[4], f32x4 (&q)[4]) {
-#pragma unroll
-                for (int G = 0; G < 4; ++G) {
-                    hb[G] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hb[G], b, zero, 0, 0, 0);
-                    q[G] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_q[G], b, zero, 0, 0, 0);
-                }
-            };
+            // results of one tile: D'' for rays 16G + 4 quad + i against sphere 16t + col
             auto look = [&](const f32x4 (&hb)[4], const f32x4 (&q)[4], float kp, int t) {
-                // D'' for rays 16G + 4 quad + i against sphere 16t + col
-                float Dv[4][4];
-                float m = -__builtin_inff();
+                float Dv[4][4], mG[4];
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) Dv[G][i] = __builtin_fmaf(hb[G][i], hb[G][i], -q[G][i]);
-                    m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(Dv[G][0], Dv[G][1]), __builtin_fmaxf(Dv[G][2], Dv[G][3])));
+                    mG[G] = __builtin_fmaxf(__builtin_fmaxf(Dv[G][0], Dv[G][1]), __builtin_fmaxf(Dv[G][2], Dv[G][3]));
                 }
+                const float m = __builtin_fmaxf(__builtin_fmaxf(mG[0], mG[1]), __builtin_fmaxf(mG[2], mG[3]));
                 if (__builtin_expect(__ballot(m >= kp) != 0ull, 0)) {
 #pragma unroll
                     for (int G = 0; G < 4; ++G) {
+                        if (__ballot(mG[G] >= kp) != 0ull) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int ray = 16 * G + 4 * quad + i;
-                            if (Dv[G][i] >= kp && ((alive_mask >> ray) & 1ull)) {
-                                const unsigned slot = atomicAdd(&s_cnt[wave * 64 + ray], 1u);
-                                if (slot < (unsigned)kCandCap) cand[slot][wave * 64 + ray] = (uint16_t)(16 * t + col);
+                            for (int i = 0; i < 4; ++i) {
+                                if (Dv[G][i] >= kp) {                   // (a dead ray can land here only
+                                    const int ray = wave * 64 + 16 * G + 4 * quad + i;   //  via K' = -inf; harmless)
+                                    const unsigned slot = atomicAdd(&s_cnt[ray], 1u);
+                                    if (slot < (unsigned)kCandCap) cand[slot][ray] = (uint16_t)(16 * t + col);
+                                }
                             }
                         }
                     }
                 }
             };
-            const int nt = P.n_tiles;
+            const int nt = P.n_tiles;                   // even; tables hold nt + 2 tiles
             f32x4 hbA[4], qA[4], hbB[4], qB[4];
-            // operands are fetched two tiles ahead of their MFMAs (L1/L2 latency off the path)
-            auto ld_b = [&](int t) { return (t < nt) ? P.bmat[t * 64 + lane] : 0.0f; };
-            auto ld_k = [&](int t) { return (t < nt) ? P.kpt[t * 16 + col] : __builtin_nanf(""); };
-            float b0 = ld_b(0), k0 = ld_k(0), b1 = ld_b(1), k1 = ld_k(1);
-            float kpA = k0, kpB = k1;
-            if (nt > 0) mfma_tile(b0, hbA, qA);
-            for (int t = 0; t < nt; t += 2) {
-                const float b2 = ld_b(t + 2), k2 = ld_k(t + 2);
-                if (t + 1 < nt) { kpB = k1; mfma_tile(b1, hbB, qB); }
-                look(hbA, qA, kpA, t);
-                const float b3 = ld_b(t + 3), k3 = ld_k(t + 3);
-                if (t + 1 < nt) {
-                    if (t + 2 < nt) { kpA = k2; mfma_tile(b2, hbA, qA); }
+            if (MODE == 2) {
+                // Tile loop, software-pipelined by hand: the 8 MFMAs of tile t+1 (4 ray groups x
+                // {HB, Q}) are issued while the VALU looks at the 16 results per lane of tile t;
+                // operands are fetched two tiles ahead of their MFMAs.
+                auto mfma_tile = [&](float b, f32x4 (&hb)[4], f32x4 (&q)[4]) {
+#pragma unroll
+                    for (int G = 0; G < 4; ++G) {
+                        hb[G] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hb[G], b, zero, 0, 0, 0);
+                        q[G] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_q[G], b, zero, 0, 0, 0);
+                    }
+                };
+                // n_tiles is even and the tables carry two spare tiles (host), so every load and
+                // every stage below is unconditional.
+                float b0 = P.bmat[lane], b1 = P.bmat[64 + lane];
+                float kpA = P.kpt[col], kpB = P.kpt[16 + col];
+                mfma_tile(b0, hbA, qA);
+                for (int t = 0; t < nt; t += 2) {
+                    const float b2 = P.bmat[(t + 2) * 64 + lane], k2 = P.kpt[(t + 2) * 16 + col];
+                    mfma_tile(b1, hbB, qB);
+                    look(hbA, qA, kpA, t);
+                    const float b3 = P.bmat[(t + 3) * 64 + lane], k3 = P.kpt[(t + 3) * 16 + col];
+                    mfma_tile(b2, hbA, qA);             // (the last one computes a spare tile: unused)
                     look(hbB, qB, kpB, t + 1);
+                    kpA = k2; kpB = k3; b1 = b3;
                 }
-                b1 = b3; k1 = k3;
+            } else {
+                bf16x8 A_hb[4], A_q[4];
+#pragma unroll
+                for (int G = 0; G < 4; ++G) { A_hb[G] = a_operand_bf16x3(a_hb[G]); A_q[G] = a_operand_bf16x3(a_q[G]); }
+                auto mfma_tile = [&](uint4 bw, f32x4 (&hb)[4], f32x4 (&q)[4]) {
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, bw);
+#pragma unroll
+                    for (int G = 0; G < 4; ++G) {
+                        hb[G] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_hb[G], b, zero, 0, 0, 0);
+                        q[G] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_q[G], b, zero, 0, 0, 0);
+                    }
+                };
+                uint4 b0 = P.bmat16[lane], b1 = P.bmat16[64 + lane];
+                float kpA = P.kpt16[col], kpB = P.kpt16[16 + col];
+                mfma_tile(b0, hbA, qA);
+                for (int t = 0; t < nt; t += 2) {
+                    const uint4 b2 = P.bmat16[(t + 2) * 64 + lane]; const float k2 = P.kpt16[(t + 2) * 16 + col];
+                    mfma_tile(b1, hbB, qB);
+                    look(hbA, qA, kpA, t);
+                    const uint4 b3 = P.bmat16[(t + 3) * 64 + lane]; const float k3 = P.kpt16[(t + 3) * 16 + col];
+                    mfma_tile(b2, hbA, qA);             // (the last one computes a spare tile: unused)
+                    look(hbB, qB, kpB, t + 1);
+                    kpA = k2; kpB = k3; b1 = b3;
+                }
             }
             __builtin_amdgcn_wave_barrier();
+            // a ray outside the analysed range keeps everything: force the test-all path
+            if (alive && !f.sane) s_cnt[tid] = (unsigned)kCandCap + 1u;
         }
         RT_STAMP(2);
         if (alive) {
@@ -296,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
 
             if (MODE == 0) {
                 for (int i = 0; i < n; ++i) { n_cand++; exact_test(i); }
-            } else if (MODE == 2) {
+            } else if (MATRIX) {
                 for (int e = 0; e < P.n_always; ++e) { n_cand++; exact_test(P.always_idx[e]); }
                 const int cnt = (int)s_cnt[tid];
                 if (cnt > kCandCap) {                   // list overflowed: test everything (rare)
@@ -505,6 +551,36 @@ __global__ void philox_kat_kernel(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
 {
     const U4 r = philox4x32_10(c0, c1, c2, c3, k0, k1);
     out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+// Known-answer hook for the matrix forms of the filter: one wave, 64 ray rows x 16 sphere
+// columns; returns HB and Q exactly as the render kernel's tiles compute them
+// (bf16x3 != 0: v_mfma_f32_16x16x32_bf16 on three-piece operands; else v_mfma_f32_16x16x4_f32).
+__global__ __launch_bounds__(64) void filter_products_kernel(const float *r1, const float *r2, const float *s,
+                                                           int bf16x3, float *hb_out, float *q_out)
+{
+    const int lane = threadIdx.x, col = lane & 15, quad = lane >> 4;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float sv = s[col * 4 + quad];                     // S[k = quad][sphere = col]
+    for (int G = 0; G < 4; ++G) {
+        const float a1 = r1[(16 * G + col) * 4 + quad];     // R[ray 16G + (l&15)][k = l>>4]
+        const float a2 = r2[(16 * G + col) * 4 + quad];
+        f32x4 hb, q;
+        if (bf16x3) {
+            const Bf3 y = split_bf16x3(sv);
+            const uint4 bw = make_uint4(y.p1 | (y.p2 << 16), y.p1 | (y.p3 << 16), y.p2 | (y.p1 << 16), y.p3 | (y.p2 << 16));
+            const bf16x8 b = __builtin_bit_cast(bf16x8, bw);
+            hb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_operand_bf16x3(a1), b, zero, 0, 0, 0);
+            q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_operand_bf16x3(a2), b, zero, 0, 0, 0);
+        } else {
+            hb = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, sv, zero, 0, 0, 0);
+            q = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, sv, zero, 0, 0, 0);
+        }
+        for (int i = 0; i < 4; ++i) {                       // result (ray 16G + 4 quad + i, sphere col)
+            hb_out[(16 * G + 4 * quad + i) * 16 + col] = hb[i];
+            q_out[(16 * G + 4 * quad + i) * 16 + col] = q[i];
+        }
+    }
 }
 
 __global__ void f64_div_sqrt_kernel(const double *a, const double *b, int n, double *q, double *r)

@@ -134,6 +134,19 @@ class Renderer:
                                                     r.ctypes.data_as(C.c_void_p)), "rt_f64_div_sqrt_device")
         return q, r
 
+    def filter_products(self, r1, r2, s, bf16x3=True):
+        """Matrix-pipe filter products HB = R1 x S^T, Q = R2 x S^T (known-answer test hook)."""
+        r1 = np.ascontiguousarray(r1, dtype=np.float32).reshape(64, 4)
+        r2 = np.ascontiguousarray(r2, dtype=np.float32).reshape(64, 4)
+        s = np.ascontiguousarray(s, dtype=np.float32).reshape(16, 4)
+        hb = np.zeros((64, 16), dtype=np.float32)
+        q = np.zeros((64, 16), dtype=np.float32)
+        _ffi.check(self._lib.rt_filter_products_device(self._h, r1.ctypes.data_as(C.c_void_p), r2.ctypes.data_as(C.c_void_p),
+                                                       s.ctypes.data_as(C.c_void_p), int(bool(bf16x3)),
+                                                       hb.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p)),
+                   "rt_filter_products_device")
+        return hb, q
+
     def philox(self, ctr, key):
         c = (C.c_uint32 * 4)(*ctr)
         k = (C.c_uint32 * 2)(*key)

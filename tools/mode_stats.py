@@ -1,0 +1,13 @@
+"""Diagnostic: candidate statistics and timing per scan mode on cfg2."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rtiow_amd as rt
+flat = rt.random_scene(1).flatten()
+for mode in (3, 2, 1):
+    for chunk in (4,):
+        os.environ["RTIOW_SCAN_MODE"] = str(mode); os.environ["RTIOW_CHUNK"] = str(chunk)
+        r = rt.Renderer(0); r.upload_scene(flat)
+        for _ in range(2):
+            sm, fix, st = r.render(rt.book1_camera(1200, 675), rt.make_params(1200, 675, 100), want_fix=False)
+        print(f"mode {mode} chunk {chunk}: {st['kernel_ms']:.2f} ms cand/ray {st['candidates']/st['rays_traced']:.3f} roots/ray {st['exact_roots']/st['rays_traced']:.3f} grid {st['grid_blocks']}", flush=True)
+        r.close()

@@ -7,7 +7,7 @@ from rtiow_amd import _ffi
 _ffi.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtiow_hip_stamps.so")
 import rtiow_amd as rt
 names = ["(a) fetch item", "(b) camera ray", "(c,d) filter scan", "(d) exact tests", "(e) shade+accumulate", "-"]
-for mode in (2, 1):
+for mode in (3, 2, 1):
     os.environ["RTIOW_SCAN_MODE"] = str(mode)
     r = rt.Renderer(0)
     r.upload_scene(rt.random_scene(1).flatten())
