@@ -23,6 +23,7 @@
 //     added to the frame buffer with 64-bit atomics once per item.
 #pragma once
 #include "rt_device.hpp"
+#include <type_traits>
 
 namespace rt {
 
@@ -63,6 +64,7 @@ constexpr int kBlock = 256;
 constexpr int kCandCap = 24;        // per-lane candidate slots
 constexpr int kScanUnroll = 8;      // spheres per overflow check
 constexpr int kItemBlock = 128;     // work items a wave reserves per atomic (>= 64)
+constexpr int kSegTiles = 36;       // matrix filter: tiles (of 16 spheres) per candidate-bitmap segment
 
 __device__ __forceinline__ D3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
 
@@ -87,7 +89,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
     __shared__ uint16_t cand[FILTERED ? kCandCap : 1][kBlock];
     constexpr bool MATRIX = (MODE == 2 || MODE == 3);
     __shared__ float s_rayop[MATRIX ? kBlock / 64 : 1][MATRIX ? 8 : 1][MATRIX ? kRowPad : 1];
-    __shared__ unsigned int s_cnt[MATRIX ? kBlock : 1];
+    // per ray, one bit per sphere of the current segment (kSegTiles tiles): set by whichever lane
+    // holds the passing result (ds_or, nothing returned, nothing waited for), read by the owner
+    __shared__ unsigned int s_bits[MATRIX ? kBlock / 64 : 1][MATRIX ? kSegTiles / 2 : 1][MATRIX ? 64 : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -200,6 +204,44 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
         // ---- (d) HittableList::hit, mod.rs:54-70 -------------------------------
         double closest = __builtin_inf();
         int hit = -1;
+        const double a = length_squared(d);                         // sphere.rs:20
+        // sphere.rs:16-34 for sphere idx, exactly as the reference computes it
+        auto exact_test = [&](int idx) {
+            const double4 g = *reinterpret_cast<const double4 *>(geo + 4 * (size_t)idx);
+            const D3 oc = o - mk(g.x, g.y, g.z);
+            const double half_b = dot(oc, d);
+            const double c = length_squared(oc) - g.w;              // g.w = radius*radius
+            const double disc = half_b * half_b - a * c;
+            if (disc < 0.0) return;                                 // sphere.rs:25
+            // Both roots are <= 0 < t_min when the origin is outside (c > 0) and the
+            // sphere lies behind the ray (half_b > 0): sqrt(disc) <= half_b, so the
+            // reference's two range tests (sphere.rs:29-33) both fail.  Skip the sqrt.
+            if (half_b > 0.0 && c > 0.0) return;
+            n_roots++;
+            const double sqrtd = __builtin_sqrt(disc);
+            // sphere.rs:28-34 + mod.rs:61-67, written so that the ORDER in which a ray's
+            // candidates are visited does not matter: the reference keeps sphere idx iff
+            // its root r* (the near root if >= t_min, else the far root) satisfies
+            // t_min <= r* <= closest-so-far, so the scan ends with the smallest r*, and among
+            // equal r* with the LAST sphere of the list.
+            double root = (-half_b - sqrtd) / a;
+            if (root < t_min) {
+                root = (-half_b + sqrtd) / a;
+                if (root < t_min) return;
+            }
+            if (root < closest || (root == closest && idx > hit)) {
+                closest = root;                                     // mod.rs:63-64
+                hit = idx;
+            }
+        };
+        // exact tests over a per-lane list of `cnt` sphere indices in cand[][tid]
+        auto test_list = [&](int cnt) {
+            // trip count = longest list among the active lanes (exec-masked vote)
+            for (int k = 0; __any(k < cnt); ++k) {
+                if (k < cnt) { n_cand++; exact_test((int)cand[k][tid]); }
+            }
+        };
+
         if (MATRIX) {
             // ---- the filter on the matrix pipe: the whole wave takes part ------------
             const int wave = tid >> 6;
@@ -214,158 +256,119 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
             rop[2 * kRowPad + lane] = -f.gz; rop[3 * kRowPad + lane] = f.h0;
             rop[4 * kRowPad + lane] = f.px;  rop[5 * kRowPad + lane] = f.py;
             rop[6 * kRowPad + lane] = f.pz;  rop[7 * kRowPad + lane] = f.o2;
-            s_cnt[tid] = 0u;
             __builtin_amdgcn_wave_barrier();            // LDS ops of one wave execute in order
+            const int col = lane & 15, quad = lane >> 4;
             // A operands: lane l holds R[ray 16G + (l&15)][k = l>>4]
-            float a_hb[4], a_q[4];
+            typedef typename std::conditional<MODE == 3, bf16x8, float>::type aop_t;
+            typedef typename std::conditional<MODE == 3, uint4, float>::type bop_t;
+            aop_t A_hb[4], A_q[4];
 #pragma unroll
             for (int G = 0; G < 4; ++G) {
-                a_hb[G] = rop[(lane >> 4) * kRowPad + 16 * G + (lane & 15)];
-                a_q[G] = rop[(4 + (lane >> 4)) * kRowPad + 16 * G + (lane & 15)];
+                const float vh = rop[quad * kRowPad + 16 * G + col];
+                const float vq = rop[(4 + quad) * kRowPad + 16 * G + col];
+                if constexpr (MODE == 3) { A_hb[G] = a_operand_bf16x3(vh); A_q[G] = a_operand_bf16x3(vq); }
+                else { A_hb[G] = vh; A_q[G] = vq; }
             }
-            const int col = lane & 15, quad = lane >> 4;
             const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-            // results of one tile: D'' for rays 16G + 4 quad + i against sphere 16t + col
-            auto look = [&](const f32x4 (&hb)[4], const f32x4 (&q)[4], float kp, int t) {
-                float Dv[4][4], mG[4];
+            const bop_t *btab;
+            const float *ktab;
+            if constexpr (MODE == 3) { btab = P.bmat16; ktab = P.kpt16; } else { btab = P.bmat; ktab = P.kpt; }
+            // the 4 MFMAs of half a tile: ray groups 2h, 2h+1 x {HB, Q}
+            auto mfma_half = [&](int h, bop_t bw, f32x4 (&hb)[2], f32x4 (&q)[2]) {
 #pragma unroll
-                for (int G = 0; G < 4; ++G) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) Dv[G][i] = __builtin_fmaf(hb[G][i], hb[G][i], -q[G][i]);
-                    mG[G] = __builtin_fmaxf(__builtin_fmaxf(Dv[G][0], Dv[G][1]), __builtin_fmaxf(Dv[G][2], Dv[G][3]));
+                for (int g = 0; g < 2; ++g) {
+                    if constexpr (MODE == 3) {
+                        const bf16x8 bb = __builtin_bit_cast(bf16x8, bw);
+                        hb[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_hb[2 * h + g], bb, zero, 0, 0, 0);
+                        q[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_q[2 * h + g], bb, zero, 0, 0, 0);
+                    } else {
+                        hb[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_hb[2 * h + g], bw, zero, 0, 0, 0);
+                        q[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_q[2 * h + g], bw, zero, 0, 0, 0);
+                    }
                 }
-                const float m = __builtin_fmaxf(__builtin_fmaxf(mG[0], mG[1]), __builtin_fmaxf(mG[2], mG[3]));
-                if (__builtin_expect(__ballot(m >= kp) != 0ull, 0)) {
+            };
+            // results of half a tile: D'' for rays 16G + 4 quad + i (G = 2h+g) against sphere 16t + col
+            auto look_half = [&](int h, const f32x4 (&hb)[2], const f32x4 (&q)[2], float kp, int trel) {
+                float Dv[2][4], mG[2];
 #pragma unroll
-                    for (int G = 0; G < 4; ++G) {
-                        if (__ballot(mG[G] >= kp) != 0ull) {
+                for (int g = 0; g < 2; ++g) {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                if (Dv[G][i] >= kp) {                   // (a dead ray can land here only
-                                    const int ray = wave * 64 + 16 * G + 4 * quad + i;   //  via K' = -inf; harmless)
-                                    const unsigned slot = atomicAdd(&s_cnt[ray], 1u);
-                                    if (slot < (unsigned)kCandCap) cand[slot][ray] = (uint16_t)(16 * t + col);
-                                }
+                    for (int i = 0; i < 4; ++i) Dv[g][i] = __builtin_fmaf(hb[g][i], hb[g][i], -q[g][i]);
+                    mG[g] = __builtin_fmaxf(__builtin_fmaxf(Dv[g][0], Dv[g][1]), __builtin_fmaxf(Dv[g][2], Dv[g][3]));
+                }
+                if (__builtin_expect(__ballot(__builtin_fmaxf(mG[0], mG[1]) >= kp) != 0ull, 0)) {
+                    const unsigned bit = 1u << ((trel & 1) * 16 + col);
+                    unsigned int *row = &s_bits[wave][trel >> 1][0];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        if (__ballot(mG[g] >= kp) != 0ull) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)             // (a ray without a path can land here
+                                if (Dv[g][i] >= kp)                 //  only via K' = -inf; harmless)
+                                    atomicOr(&row[16 * (2 * h + g) + 4 * quad + i], bit);
+                        }
+                    }
+                }
+            };
+            if (alive) {
+                for (int e = 0; e < P.n_always; ++e) { n_cand++; exact_test(P.always_idx[e]); }
+                // outside the analysed range: everything is tested exactly
+                if (!f.sane) for (int i = 0; i < n; ++i) { n_cand++; exact_test(i); }
+            }
+            const int nt = P.n_tiles;                   // even; the tables hold nt + 2 tiles
+            for (int seg0 = 0; seg0 < nt; seg0 += kSegTiles) {
+                const int seg_n = min(kSegTiles, nt - seg0);
+                const int nwords = seg_n >> 1;
+                for (int w = 0; w < nwords; ++w) s_bits[wave][w][lane] = 0u;
+                __builtin_amdgcn_wave_barrier();
+                // Software pipeline over half tiles: the 4 MFMAs of the next half are issued
+                // before the VALU looks at the 8 results per lane of the previous one; the B
+                // operand and K' of a tile are fetched a whole tile ahead.
+                f32x4 hbA[2], qA[2], hbB[2], qB[2];
+                bop_t b_cur = btab[seg0 * 64 + lane], b_next = btab[(seg0 + 1) * 64 + lane];
+                float k_cur = ktab[seg0 * 16 + col], k_next = ktab[(seg0 + 1) * 16 + col];
+                mfma_half(0, b_cur, hbA, qA);
+                for (int tr = 0; tr < seg_n; ++tr) {
+                    const bop_t b_nn = btab[(seg0 + tr + 2) * 64 + lane];
+                    const float k_nn = ktab[(seg0 + tr + 2) * 16 + col];
+                    mfma_half(1, b_cur, hbB, qB);
+                    look_half(0, hbA, qA, k_cur, tr);
+                    mfma_half(0, b_next, hbA, qA);      // (the last one computes a spare tile: unused)
+                    look_half(1, hbB, qB, k_cur, tr);
+                    b_cur = b_next; b_next = b_nn; k_cur = k_next; k_next = k_nn;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (alive) {
+                    // the owner turns its bitmap into a list, then runs the exact tests
+                    int cnt = 0;
+                    for (int w = 0; w < nwords; ++w) {
+                        unsigned word = s_bits[wave][w][lane];
+                        while (__any(word != 0u)) {
+                            if (word != 0u) {
+                                const int bpos = __builtin_ctz(word);
+                                word &= word - 1u;
+                                if (cnt < kCandCap) cand[cnt][tid] = (uint16_t)(16 * seg0 + 32 * w + bpos);
+                                cnt++;
                             }
                         }
                     }
-                }
-            };
-            const int nt = P.n_tiles;                   // even; tables hold nt + 2 tiles
-            f32x4 hbA[4], qA[4], hbB[4], qB[4];
-            if (MODE == 2) {
-                // Tile loop, software-pipelined by hand: the 8 MFMAs of tile t+1 (4 ray groups x
-                // {HB, Q}) are issued while the VALU looks at the 16 results per lane of tile t;
-                // operands are fetched two tiles ahead of their MFMAs.
-                auto mfma_tile = [&](float b, f32x4 (&hb)[4], f32x4 (&q)[4]) {
-#pragma unroll
-                    for (int G = 0; G < 4; ++G) {
-                        hb[G] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hb[G], b, zero, 0, 0, 0);
-                        q[G] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_q[G], b, zero, 0, 0, 0);
+                    if (cnt > kCandCap) {               // list overflowed: test the whole segment (rare)
+                        const int i1 = min(n, 16 * (seg0 + seg_n));
+                        for (int i = 16 * seg0; i < i1; ++i) { n_cand++; exact_test(i); }
+                    } else {
+                        test_list(cnt);
                     }
-                };
-                // n_tiles is even and the tables carry two spare tiles (host), so every load and
-                // every stage below is unconditional.
-                float b0 = P.bmat[lane], b1 = P.bmat[64 + lane];
-                float kpA = P.kpt[col], kpB = P.kpt[16 + col];
-                mfma_tile(b0, hbA, qA);
-                for (int t = 0; t < nt; t += 2) {
-                    const float b2 = P.bmat[(t + 2) * 64 + lane], k2 = P.kpt[(t + 2) * 16 + col];
-                    mfma_tile(b1, hbB, qB);
-                    look(hbA, qA, kpA, t);
-                    const float b3 = P.bmat[(t + 3) * 64 + lane], k3 = P.kpt[(t + 3) * 16 + col];
-                    mfma_tile(b2, hbA, qA);             // (the last one computes a spare tile: unused)
-                    look(hbB, qB, kpB, t + 1);
-                    kpA = k2; kpB = k3; b1 = b3;
-                }
-            } else {
-                bf16x8 A_hb[4], A_q[4];
-#pragma unroll
-                for (int G = 0; G < 4; ++G) { A_hb[G] = a_operand_bf16x3(a_hb[G]); A_q[G] = a_operand_bf16x3(a_q[G]); }
-                auto mfma_tile = [&](uint4 bw, f32x4 (&hb)[4], f32x4 (&q)[4]) {
-                    const bf16x8 b = __builtin_bit_cast(bf16x8, bw);
-#pragma unroll
-                    for (int G = 0; G < 4; ++G) {
-                        hb[G] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_hb[G], b, zero, 0, 0, 0);
-                        q[G] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_q[G], b, zero, 0, 0, 0);
-                    }
-                };
-                uint4 b0 = P.bmat16[lane], b1 = P.bmat16[64 + lane];
-                float kpA = P.kpt16[col], kpB = P.kpt16[16 + col];
-                mfma_tile(b0, hbA, qA);
-                for (int t = 0; t < nt; t += 2) {
-                    const uint4 b2 = P.bmat16[(t + 2) * 64 + lane]; const float k2 = P.kpt16[(t + 2) * 16 + col];
-                    mfma_tile(b1, hbB, qB);
-                    look(hbA, qA, kpA, t);
-                    const uint4 b3 = P.bmat16[(t + 3) * 64 + lane]; const float k3 = P.kpt16[(t + 3) * 16 + col];
-                    mfma_tile(b2, hbA, qA);             // (the last one computes a spare tile: unused)
-                    look(hbB, qB, kpB, t + 1);
-                    kpA = k2; kpB = k3; b1 = b3;
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            // a ray outside the analysed range keeps everything: force the test-all path
-            if (alive && !f.sane) s_cnt[tid] = (unsigned)kCandCap + 1u;
         }
         RT_STAMP(2);
-        if (alive) {
-            const double a = length_squared(d);                     // sphere.rs:20
-            // sphere.rs:16-34 for sphere idx, exactly as the reference computes it
-            auto exact_test = [&](int idx) {
-                const double4 g = *reinterpret_cast<const double4 *>(geo + 4 * (size_t)idx);
-                const D3 oc = o - mk(g.x, g.y, g.z);
-                const double half_b = dot(oc, d);
-                const double c = length_squared(oc) - g.w;          // g.w = radius*radius
-                const double disc = half_b * half_b - a * c;
-                if (disc < 0.0) return;                             // sphere.rs:25
-                // Both roots are <= 0 < t_min when the origin is outside (c > 0) and the
-                // sphere lies behind the ray (half_b > 0): sqrt(disc) <= half_b, so the
-                // reference's two range tests (sphere.rs:29-33) both fail.  Skip the sqrt.
-                if (half_b > 0.0 && c > 0.0) return;
-                n_roots++;
-                const double sqrtd = __builtin_sqrt(disc);
-                // sphere.rs:28-34 + mod.rs:61-67, written so that the ORDER in which a ray's
-                // candidates are visited does not matter: the reference keeps sphere idx iff
-                // its root r* (the near root if >= t_min, else the far root) satisfies
-                // t_min <= r* <= closest-so-far, so the scan ends with the smallest r*, and among
-                // equal r* with the LAST sphere of the list.
-                double root = (-half_b - sqrtd) / a;
-                if (root < t_min) {
-                    root = (-half_b + sqrtd) / a;
-                    if (root < t_min) return;
-                }
-                if (root < closest || (root == closest && idx > hit)) {
-                    closest = root;                                 // mod.rs:63-64
-                    hit = idx;
-                }
-            };
-
+        if (alive && !MATRIX) {
             if (MODE == 0) {
                 for (int i = 0; i < n; ++i) { n_cand++; exact_test(i); }
-            } else if (MATRIX) {
-                for (int e = 0; e < P.n_always; ++e) { n_cand++; exact_test(P.always_idx[e]); }
-                const int cnt = (int)s_cnt[tid];
-                if (cnt > kCandCap) {                   // list overflowed: test everything (rare)
-                    for (int i = 0; i < n; ++i) { n_cand++; exact_test(i); }
-                } else {
-                    for (int k = 0; __any(k < cnt); ++k) {
-                        if (k < cnt) { n_cand++; exact_test((int)cand[k][tid]); }
-                    }
-                }
             } else {
                 const RayFilter f = make_filter(o, d);
                 int cnt = 0;
-                auto drain = [&]() {
-                    // trip count = longest list among the active lanes (exec-masked vote:
-                    // no cross-lane data movement inside this divergent region)
-                    for (int k = 0; __any(k < cnt); ++k) {
-                        if (k < cnt) {
-                            n_cand++;
-                            exact_test((int)cand[k][tid]);
-                        }
-                    }
-                    cnt = 0;
-                };
+                auto drain = [&]() { test_list(cnt); cnt = 0; };
                 // One filter test.  Candidates are rare per sphere (about one wave-test in ten
                 // has any), so the push sits behind a wave-level branch that is normally not taken.
                 auto test = [&](float cx, float cy, float cz, float kp, int i) {
