@@ -92,6 +92,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
     // per ray, one bit per sphere of the current segment (kSegTiles tiles): set by whichever lane
     // holds the passing result (ds_or, nothing returned, nothing waited for), read by the owner
     __shared__ unsigned int s_bits[MATRIX ? kBlock / 64 : 1][MATRIX ? kSegTiles / 2 : 1][MATRIX ? 64 : 1];
+    __shared__ unsigned int s_sum[MATRIX ? kBlock : 1];     // per ray: which of its bitmap words are non-zero
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
 #ifdef RT_PHASE_STAMPS
     // Diagnostic build only (never the shipped library): wave-time spent per phase, summed
     // into stats[8..15].  The stamps serialise the phases; read the SHARES, not the total.
-    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #define RT_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); \
                          __builtin_amdgcn_s_waitcnt(0); ph[k] += tn_ - tprev; tprev = tn_; } while (0)
 #else
@@ -298,14 +299,19 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
                 }
                 if (__builtin_expect(__ballot(__builtin_fmaxf(mG[0], mG[1]) >= kp) != 0ull, 0)) {
                     const unsigned bit = 1u << ((trel & 1) * 16 + col);
+                    const unsigned wbit = 1u << (trel >> 1);
                     unsigned int *row = &s_bits[wave][trel >> 1][0];
+                    unsigned int *sum = &s_sum[wave * 64];
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
                         if (__ballot(mG[g] >= kp) != 0ull) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i)             // (a ray without a path can land here
-                                if (Dv[g][i] >= kp)                 //  only via K' = -inf; harmless)
-                                    atomicOr(&row[16 * (2 * h + g) + 4 * quad + i], bit);
+                                if (Dv[g][i] >= kp) {               //  only via K' = -inf; harmless)
+                                    const int ray = 16 * (2 * h + g) + 4 * quad + i;
+                                    atomicOr(&row[ray], bit);
+                                    atomicOr(&sum[ray], wbit);
+                                }
                         }
                     }
                 }
@@ -316,10 +322,12 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
                 if (!f.sane) for (int i = 0; i < n; ++i) { n_cand++; exact_test(i); }
             }
             const int nt = P.n_tiles;                   // even; the tables hold nt + 2 tiles
+            RT_STAMP(5);
             for (int seg0 = 0; seg0 < nt; seg0 += kSegTiles) {
                 const int seg_n = min(kSegTiles, nt - seg0);
                 const int nwords = seg_n >> 1;
                 for (int w = 0; w < nwords; ++w) s_bits[wave][w][lane] = 0u;
+                s_sum[tid] = 0u;
                 __builtin_amdgcn_wave_barrier();
                 // Software pipeline over half tiles: the 4 MFMAs of the next half are issued
                 // before the VALU looks at the 8 results per lane of the previous one; the B
@@ -338,25 +346,26 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
                     b_cur = b_next; b_next = b_nn; k_cur = k_next; k_next = k_nn;
                 }
                 __builtin_amdgcn_wave_barrier();
+                RT_STAMP(6);
                 if (alive) {
-                    // the owner turns its bitmap into a list, then runs the exact tests
-                    int cnt = 0;
-                    for (int w = 0; w < nwords; ++w) {
-                        unsigned word = s_bits[wave][w][lane];
-                        while (__any(word != 0u)) {
-                            if (word != 0u) {
-                                const int bpos = __builtin_ctz(word);
-                                word &= word - 1u;
-                                if (cnt < kCandCap) cand[cnt][tid] = (uint16_t)(16 * seg0 + 32 * w + bpos);
-                                cnt++;
+                    // The owner walks its candidates straight off the bitmap, in ascending sphere
+                    // order: `summary` says which words are non-zero, `word` holds the bits left
+                    // in the current one.  Trip count = the longest candidate list in the wave.
+                    unsigned summary = s_sum[tid], word = 0u;
+                    int wbase = 0;
+                    while (__any((summary | word) != 0u)) {
+                        if ((summary | word) != 0u) {
+                            if (word == 0u) {
+                                const int w = __builtin_ctz(summary);
+                                summary &= summary - 1u;
+                                word = s_bits[wave][w][lane];
+                                wbase = 16 * seg0 + 32 * w;
                             }
+                            const int bpos = __builtin_ctz(word);
+                            word &= word - 1u;
+                            n_cand++;
+                            exact_test(wbase + bpos);
                         }
-                    }
-                    if (cnt > kCandCap) {               // list overflowed: test the whole segment (rare)
-                        const int i1 = min(n, 16 * (seg0 + seg_n));
-                        for (int i = 16 * seg0; i < i1; ++i) { n_cand++; exact_test(i); }
-                    } else {
-                        test_list(cnt);
                     }
                 }
             }
@@ -485,7 +494,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
         // (end of the bounce loop body is stamped at the top of the next iteration as phase 4)
     // wave totals -> device counters
 #ifdef RT_PHASE_STAMPS
-    if (lane == 0) for (int k = 0; k < 6; ++k) atomicAdd(P.stats + 8 + k, ph[k]);
+    if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(P.stats + 8 + k, ph[k]);
 #endif
     {
         unsigned long long ns = n_samples, nc = n_cand, nr = n_roots;

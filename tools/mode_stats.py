@@ -1,10 +1,13 @@
 """Diagnostic: candidate statistics and timing per scan mode on cfg2."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa
+from rtiow_amd import _ffi
+if os.environ.get('RTIOW_LIB'): _ffi.LIB_PATH = os.environ['RTIOW_LIB']
 import rtiow_amd as rt
 flat = rt.random_scene(1).flatten()
-for mode in (3, 2, 1):
-    for chunk in (4,):
+for mode in [int(x) for x in os.environ.get('MODES', '3,2,1').split(',')]:
+    for chunk in [int(x) for x in os.environ.get('CHUNKS', '4').split(',')]:
         os.environ["RTIOW_SCAN_MODE"] = str(mode); os.environ["RTIOW_CHUNK"] = str(chunk)
         r = rt.Renderer(0); r.upload_scene(flat)
         for _ in range(2):

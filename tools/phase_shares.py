@@ -6,8 +6,8 @@ import torch  # noqa
 from rtiow_amd import _ffi
 _ffi.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtiow_hip_stamps.so")
 import rtiow_amd as rt
-names = ["(a) fetch item", "(b) camera ray", "(c,d) filter scan", "(d) exact tests", "(e) shade+accumulate", "-"]
-for mode in (3, 2, 1):
+names = ["(a) fetch item", "(b) camera ray", "(d) exact tests (list)", "-", "(e) shade+accumulate", "(d) operands + always-exact", "(d) matrix tile loop", "(d) bitmap -> list"]
+for mode in (3,):
     os.environ["RTIOW_SCAN_MODE"] = str(mode)
     r = rt.Renderer(0)
     r.upload_scene(rt.random_scene(1).flatten())
@@ -16,8 +16,8 @@ for mode in (3, 2, 1):
     out = (C.c_ulonglong * 8)()
     r._lib.rt_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     r._lib.rt_debug_phase_cycles(r._h, out)
-    tot = sum(out[:5])
+    tot = sum(out[:8])
     print(f"scan mode {mode}: kernel {st['kernel_ms']:.2f} ms (stamped build), wave-time shares:")
-    for k in range(5):
+    for k in range(8):
         print(f"   {names[k]:24s} {100.0 * out[k] / tot:6.2f} %   {out[k] / max(1, st['rays_traced'] / 64):10.0f} ticks per wave-iteration")
     r.close()
