@@ -38,17 +38,30 @@ FLOP_PER_TEST = 17                     # per ray-sphere test
 FLOP_PER_RAY_FIXED = 65                # hit finalisation + shading per ray
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(flat, width, height, spp, target_seconds=12.0):
     """Oracle A on a bounded, evenly strided row subset of the same frame."""
     import oracle
     cam = oracle.book1_camera(width, height)
+    threads = host_cpu_share()
     probe_step = 64
-    p = oracle.make_params(width, height, spp, rows=(0, height, probe_step))
+    p = oracle.make_params(width, height, spp, rows=(0, height, probe_step), nthreads=threads)
     _, st = oracle.render_a(cam, flat, p)
     rate = st["samples"] / st["seconds"]
     rows_wanted = max(1.0, target_seconds * rate / (width * spp))
     step = int(min(probe_step, max(1, round(height / rows_wanted))))
-    p = oracle.make_params(width, height, spp, rows=(0, height, step))
+    p = oracle.make_params(width, height, spp, rows=(0, height, step), nthreads=threads)
     _, st = oracle.render_a(cam, flat, p)
     nrows = oracle.n_rows(p)
     return {
@@ -146,7 +159,7 @@ def main():
         achieved = flops / (k_ms * 1e-3) / 1e12
         algo_bytes = len(rows) * W * 12 + n_sph * 36
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
@@ -172,7 +185,7 @@ def main():
                 "rays_per_sample": round(rays / max(1, samples), 4),
             },
             "roofline": {
-                "bound": "valu", "kernel": "rt::render_kernel<true>",
+                "bound": "valu", "kernel": "rt::render_kernel<3>",
                 "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4),
                 "traffic": traffic,

@@ -126,3 +126,43 @@ def test_gpu_reproduces_the_reference_png_sky_rows(renderer, book1_flat):
             assert rgba[pt["y"], pt["x"], :3].tolist() == pt["rgb"]
     m = rgba[..., :3].reshape(-1, 3).mean(0)                        # loose sanity band only
     assert np.abs(m - np.array(fx["image_mean_rgb"])).max() < 15
+
+
+def test_all_scan_filters_give_the_same_bits(book1_flat, cfg2):
+    """The three filter implementations (VALU + scalar loads, f32 MFMA, bf16x3 MFMA) are three
+    ways of discarding spheres the reference cannot hit: the frame must not depend on which runs."""
+    w, h, spp, fix, st = cfg2
+    cands = {}
+    for mode in ("1", "2", "3"):
+        os.environ["RTIOW_SCAN_MODE"] = mode
+        try:
+            r = rt.Renderer(0)
+            r.upload_scene(book1_flat)
+            _, got, st2 = r.render(rt.book1_camera(w, h), rt.make_params(w, h, spp))
+            r.close()
+        finally:
+            os.environ.pop("RTIOW_SCAN_MODE")
+        assert np.array_equal(got, fix), mode
+        assert st2["rays_traced"] == st["rays_traced"] and st2["exact_roots"] == st["exact_roots"]
+        cands[mode] = st2["candidates"]
+    assert cands["1"] <= cands["2"] * 1.2 and cands["2"] <= cands["3"] * 1.01   # looser KU keeps more
+
+
+def test_tenk_scene_full_size_properties(renderer):
+    """BASELINE.json configs[3] (10 001 spheres, 1920x1080) at reduced spp: sharding + pass
+    invariance with several bitmap segments per ray in play."""
+    flat = rt.random_scene(1, grid=(-50, 49)).flatten()
+    renderer.upload_scene(flat)
+    w, h, spp = 1920, 1080, 2
+    cam = rt.book1_camera(w, h)
+    _, whole, st = renderer.render(cam, rt.make_params(w, h, spp))
+    acc = np.zeros_like(whole)
+    for k in range(4):
+        p = rt.make_params(w, h, spp, tile_rows=16, shard_index=k, shard_count=4)
+        _, part, _ = renderer.render(cam, p)
+        acc[shard_row_map(h, 16, k, 4)] = part
+    assert np.array_equal(acc, whole)
+    _, p0, _ = renderer.render(cam, rt.make_params(w, h, 1))
+    _, p1, _ = renderer.render(cam, rt.make_params(w, h, 1, sample_begin=1))
+    assert np.array_equal(p0 + p1, whole)
+    assert st["samples"] == w * h * spp
