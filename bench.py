@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--spp", type=int, default=100, help="samples per pixel PER GPU-share (frame spp = spp x N)")
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N>1 logic check on a 1-GPU box: every rank renders on cuda:0 and the gather runs "
+                         "over gloo on CPU tensors (RCCL refuses two ranks on one device); not a measurement")
     args = ap.parse_args()
 
     import torch
@@ -97,11 +100,16 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
         args.gpus = world
     dist = None
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     W, H = args.width, args.height
     spp_frame = args.spp * world                       # weak scaling: per-GPU samples fixed
@@ -123,9 +131,14 @@ def main():
     def step(record):
         nonlocal rays, samples
         renderer.render_device(cam, params, d_fix.data_ptr(), stream)
-        full = gather_frame(d_fix, H, args.tile_rows, rank, world)
+        if args.rehearse_on_one_gpu and world > 1:
+            full = gather_frame(d_fix.cpu(), H, args.tile_rows, rank, world)
+            full = full.to(dev) if rank == 0 else None
+        else:
+            full = gather_frame(d_fix, H, args.tile_rows, rank, world)
         if rank == 0:
             renderer.resolve_rgba8_device(full.data_ptr(), W, H, spp_frame, 1, d_rgba.data_ptr(), stream)
+            step.last_full = full
         if record:
             st = renderer.last_stats()                 # waits for this launch's events only
             kernel_ms.append(st["kernel_ms"])
@@ -137,6 +150,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    step.last_full = None
+
     for _ in range(args.warmup):
         step(False)
     fence()
@@ -146,7 +161,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -167,6 +182,10 @@ def main():
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        frame_crc = None
+        if step.last_full is not None:
+            import zlib
+            frame_crc = zlib.crc32(step.last_full.cpu().numpy().tobytes()) & 0xFFFFFFFF
         out = {
             "metric": "Msamples/sec (pixels x spp) on book-1 final scene",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world,
@@ -183,6 +202,7 @@ def main():
                 "sharding": "whole frame on one GPU" if world == 1 else
                             f"row tiles of {args.tile_rows} dealt round-robin to {world} ranks, one RCCL gather",
                 "rays_per_sample": round(rays / max(1, samples), 4),
+                "frame_crc32": frame_crc,      # of the exact sums: equal for equal (W, H, spp) at any N
             },
             "roofline": {
                 "bound": "valu", "kernel": "rt::render_kernel<3>",
