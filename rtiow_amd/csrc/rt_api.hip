@@ -74,6 +74,7 @@ struct rt_context {
     void *d_stage_rgba = nullptr; size_t stage_rgba_bytes = 0;
     int blocks_per_cu = 0;     // 0 = occupancy query
     int chunk = 0;             // 0 = default
+    int item_block = rt::kItemBlock;
 };
 
 namespace {
@@ -170,6 +171,8 @@ int rt_create(int32_t device_id, rt_context **out)
     ctx->cu_count = prop.multiProcessorCount;
     ctx->blocks_per_cu = env_int("RTIOW_BLOCKS_PER_CU", 0);
     ctx->chunk = env_int("RTIOW_CHUNK", 0);
+    ctx->item_block = env_int("RTIOW_ITEM_BLOCK", rt::kItemBlock);
+    if (ctx->item_block < 64) ctx->item_block = 64;
     ctx->scan_mode = env_int("RTIOW_SCAN_MODE", 3);
     if (ctx->scan_mode < 1 || ctx->scan_mode > 3) ctx->scan_mode = 3;
     hipError_t e1 = hipMalloc((void **)&ctx->d_queue, 64);
@@ -382,6 +385,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.k0 = (uint32_t)p->seed; kp.k1 = (uint32_t)(p->seed >> 32);
     kp.tile_rows = p->tile_rows; kp.shard_index = p->shard_index; kp.shard_count = p->shard_count;
     kp.rows = rows; kp.n_spheres = ctx->n_spheres; kp.chunk = chunk;
+    kp.item_block = ctx->item_block;
     kp.npix = (uint32_t)npix; kp.total_items = (uint32_t)(npix * nchunks);
     kp.filt = ctx->d_filt; kp.geo = ctx->d_geo; kp.mat = ctx->d_mat;
     kp.bmat = ctx->d_bmat; kp.kpt = ctx->d_kpt; kp.n_tiles = ctx->n_tiles;

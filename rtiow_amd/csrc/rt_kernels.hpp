@@ -42,6 +42,7 @@ struct KParams {
     int32_t rows;              // compact rows of this shard
     int32_t n_spheres;
     int32_t chunk;             // samples per work item
+    int32_t item_block;        // work items a wave reserves per atomic (>= 64)
     uint32_t npix;             // rows * width
     uint32_t total_items;      // npix * ceil(spp / chunk)
     const float *filt;         // [n][4]  f32 filter record (cx, cy, cz, K')
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
     bool has_item = false, dead = false, alive = false;
     uint32_t pix_local = 0, pix_global = 0;
     int s = 0, s_end = 0;
-    double fi = 0.0, fj = 0.0;
+    uint32_t px_i = 0, px_j = 0;
     unsigned long long acc0 = 0, acc1 = 0, acc2 = 0;
     D3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1, 1, 1);
     int depth = 0;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
                 uint32_t newbase = 0;
                 if (cnt > avail) {                                  // wave-uniform
                     const int leader = (int)__builtin_ctzll(m);
-                    if (lane == leader) newbase = atomicAdd(P.queue, (unsigned)kItemBlock);
+                    if (lane == leader) newbase = atomicAdd(P.queue, (unsigned)P.item_block);
                     newbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(newbase, leader));
                 }
                 if (want) {
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
                         const uint32_t j = (lt * (uint32_t)P.shard_count + (uint32_t)P.shard_index) * (uint32_t)P.tile_rows
                                            + (rr - lt * (uint32_t)P.tile_rows);
                         pix_global = j * (uint32_t)P.width + i;
-                        fi = (double)i; fj = (double)j;
+                        px_i = i; px_j = j;
                         s = P.sample_begin + (int)c * P.chunk;
                         s_end = min(s + P.chunk, P.sample_begin + P.spp);
                         has_item = true;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
                         dead = true;
                     }
                 }
-                if (cnt > avail) { wave_next = newbase + (cnt - avail); wave_end = newbase + (uint32_t)kItemBlock; }
+                if (cnt > avail) { wave_next = newbase + (cnt - avail); wave_end = newbase + (uint32_t)P.item_block; }
                 else wave_next += cnt;
             }
         }
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
         if (has_item && !alive) {
             U4 w = philox4x32_10(pix_global, (uint32_t)s, 0u, 0u, P.k0, P.k1);
             ev = 1u;
-            const double u = (fi + u01(w.x)) / wm1;                 // main.rs:131
-            const double v = (fj + u01(w.y)) / hm1;                 // main.rs:132
+            const double u = ((double)px_i + u01(w.x)) / wm1;       // main.rs:131
+            const double v = ((double)px_j + u01(w.y)) / hm1;       // main.rs:132
             double lx = u11(w.z), ly = u11(w.w);
             while (!(length_squared(mk(lx, ly, 0.0)) < 1.0)) {      // vec3.rs:59-68
                 w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);

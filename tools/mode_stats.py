@@ -8,9 +8,11 @@ import rtiow_amd as rt
 flat = rt.random_scene(1).flatten()
 for mode in [int(x) for x in os.environ.get('MODES', '3,2,1').split(',')]:
     for chunk in [int(x) for x in os.environ.get('CHUNKS', '4').split(',')]:
+      for ib in [int(x) for x in os.environ.get('IBS', '128').split(',')]:
+        os.environ['RTIOW_ITEM_BLOCK'] = str(ib)
         os.environ["RTIOW_SCAN_MODE"] = str(mode); os.environ["RTIOW_CHUNK"] = str(chunk)
         r = rt.Renderer(0); r.upload_scene(flat)
         for _ in range(2):
             sm, fix, st = r.render(rt.book1_camera(1200, 675), rt.make_params(1200, 675, 100), want_fix=False)
-        print(f"mode {mode} chunk {chunk}: {st['kernel_ms']:.2f} ms cand/ray {st['candidates']/st['rays_traced']:.3f} roots/ray {st['exact_roots']/st['rays_traced']:.3f} grid {st['grid_blocks']}", flush=True)
+        print(f"mode {mode} chunk {chunk} item_block {ib}: {st['kernel_ms']:.2f} ms cand/ray {st['candidates']/st['rays_traced']:.3f} roots/ray {st['exact_roots']/st['rays_traced']:.3f} grid {st['grid_blocks']}", flush=True)
         r.close()
