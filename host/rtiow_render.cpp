@@ -1,0 +1,77 @@
+// rtiow_render -- the reference's main() (src/main.rs:104-177) on the GPU path: build the scene,
+// build the camera, render through the C ABI, flip + to_rgba, write the image (P6 PPM instead of
+// the image crate's PNG; no preview window).
+//
+//   rtiow_render [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--scene-seed S]
+//                [--grid LO HI] [--device K] [--out image.ppm] [--dump-scene scene.bin]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "rtiow_host.hpp"
+
+static int die(const char *what, int rc)
+{
+    std::fprintf(stderr, "%s failed (%d): %s\n", what, rc, rt_last_error());
+    return 1;
+}
+
+int main(int argc, char **argv)
+{
+    int width = 400, height = 225, spp = 10, depth = 50, device = 0, lo = -11, hi = 11;
+    unsigned long long seed = 1, scene_seed = 1;
+    std::string out = "image.ppm", dump;
+    for (int i = 1; i < argc; ++i) {
+        auto arg = [&](const char *n) { return !std::strcmp(argv[i], n) && i + 1 < argc; };
+        if (arg("--width")) width = std::atoi(argv[++i]);
+        else if (arg("--height")) height = std::atoi(argv[++i]);
+        else if (arg("--spp")) spp = std::atoi(argv[++i]);
+        else if (arg("--depth")) depth = std::atoi(argv[++i]);
+        else if (arg("--seed")) seed = std::strtoull(argv[++i], nullptr, 0);
+        else if (arg("--scene-seed")) scene_seed = std::strtoull(argv[++i], nullptr, 0);
+        else if (arg("--device")) device = std::atoi(argv[++i]);
+        else if (arg("--out")) out = argv[++i];
+        else if (arg("--dump-scene")) dump = argv[++i];
+        else if (!std::strcmp(argv[i], "--grid") && i + 2 < argc) { lo = std::atoi(argv[++i]); hi = std::atoi(argv[++i]); }
+        else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+    }
+    const rtiow::HittableList world = rtiow::random_scene(scene_seed, lo, hi);      // main.rs:106
+    const std::vector<rt_sphere> flat = world.flatten();
+    if (!dump.empty()) {                         // the flat scene file: count + 72-byte records
+        FILE *f = std::fopen(dump.c_str(), "wb");
+        if (!f) { std::perror(dump.c_str()); return 1; }
+        std::fwrite(flat.data(), sizeof(rt_sphere), flat.size(), f);
+        std::fclose(f);
+        std::printf("%zu spheres -> %s\n", flat.size(), dump.c_str());
+        return 0;
+    }
+    const rtiow::Camera cam(rtiow::Point3(13, 2, 3), rtiow::Point3(0, 0, 0), rtiow::Vec3(0, 1, 0), 20.0,
+                            (double)width / (double)height, 0.1, 10.0);             // main.rs:108-118
+    rt_context *ctx = nullptr;
+    int rc = rt_create(device, &ctx);
+    if (rc) return die("rt_create", rc);
+    rc = rt_upload_scene(ctx, flat.data(), (int32_t)flat.size());
+    if (rc) return die("rt_upload_scene", rc);
+    rt_params p{};
+    p.width = width; p.height = height; p.spp = spp; p.sample_begin = 0; p.max_depth = depth;
+    p.t_min = 0.0001; p.seed = seed; p.tile_rows = 8; p.shard_index = 0; p.shard_count = 1; p.flags = 0;
+    const size_t npix = (size_t)width * height;
+    std::vector<uint64_t> fix(npix * 3);
+    const rt_camera rc_cam = cam.flat();
+    rt_stats st{};
+    rc = rt_render(ctx, &rc_cam, &p, nullptr, fix.data(), &st);                      // main.rs:122-136
+    if (rc) return die("rt_render", rc);
+    std::vector<uint8_t> rgba(npix * 4);
+    rc = rt_resolve_rgba8(ctx, fix.data(), width, height, spp, 1, rgba.data());      // main.rs:137,141-145
+    if (rc) return die("rt_resolve_rgba8", rc);
+    rt_destroy(ctx);
+    FILE *f = std::fopen(out.c_str(), "wb");
+    if (!f) { std::perror(out.c_str()); return 1; }
+    std::fprintf(f, "P6\n%d %d\n255\n", width, height);
+    for (size_t k = 0; k < npix; ++k) std::fwrite(&rgba[4 * k], 1, 3, f);
+    std::fclose(f);
+    std::printf("%dx%d spp %d: %llu rays, kernel %.3f ms (%.1f Msamples/s) -> %s\n", width, height, spp,
+                (unsigned long long)st.rays_traced, st.kernel_ms, npix * (double)spp / st.kernel_ms / 1e3, out.c_str());
+    return 0;
+}
