@@ -84,7 +84,9 @@ constexpr int kRowPad = 80;         // floats per row of the ray-operand transpo
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
+// second launch bound = waves per SIMD the register allocator must leave room for: the bounce loop
+// is latency-bound, and the 4th wave is worth more than the few cold values it spills
+__global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void render_kernel(const KParams P)
 {
     constexpr bool FILTERED = (MODE != 0);
     __shared__ uint16_t cand[FILTERED ? kCandCap : 1][kBlock];
@@ -119,7 +121,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
     D3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1, 1, 1);
     int depth = 0;
     uint32_t ev = 0;
-    uint32_t n_rays = 0, n_samples = 0, n_cand = 0, n_roots = 0;
+    uint32_t n_rays = 0, n_samples = 0;
+    unsigned long long tot_cand = 0, tot_roots = 0;     // wave totals (uniform)
     uint32_t wave_next = 0, wave_end = 0;          // this wave's reserved block of work items (uniform)
 
 #ifdef RT_PHASE_STAMPS
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
         // ---- (d) HittableList::hit, mod.rs:54-70 -------------------------------
         double closest = __builtin_inf();
         int hit = -1;
+        uint32_t n_cand = 0, n_roots = 0;                           // this bounce, this lane
         const double a = length_squared(d);                         // sphere.rs:20
         // sphere.rs:16-34 for sphere idx, exactly as the reference computes it
         auto exact_test = [&](int idx) {
@@ -330,21 +334,21 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
                 for (int w = 0; w < nwords; ++w) s_bits[wave][w][lane] = 0u;
                 s_sum[tid] = 0u;
                 __builtin_amdgcn_wave_barrier();
-                // Software pipeline over half tiles: the 4 MFMAs of the next half are issued
-                // before the VALU looks at the 8 results per lane of the previous one; the B
-                // operand and K' of a tile are fetched a whole tile ahead.
-                f32x4 hbA[2], qA[2], hbB[2], qB[2];
-                bop_t b_cur = btab[seg0 * 64 + lane], b_next = btab[(seg0 + 1) * 64 + lane];
-                float k_cur = ktab[seg0 * 16 + col], k_next = ktab[(seg0 + 1) * 16 + col];
-                mfma_half(0, b_cur, hbA, qA);
+                // Half a tile at a time: 4 MFMAs (2 ray groups x {HB, Q}), then the VALU looks at the
+                // 8 results per lane.  No software pipelining inside the wave: with 4 waves per SIMD
+                // the other waves fill the matrix pipe while this one looks (and registers are what
+                // buys the 4th wave).  B operand and K' of the next tile are fetched a tile ahead.
+                f32x4 hbA[2], qA[2];
+                bop_t b_cur = btab[seg0 * 64 + lane];
+                float k_cur = ktab[seg0 * 16 + col];
                 for (int tr = 0; tr < seg_n; ++tr) {
-                    const bop_t b_nn = btab[(seg0 + tr + 2) * 64 + lane];
-                    const float k_nn = ktab[(seg0 + tr + 2) * 16 + col];
-                    mfma_half(1, b_cur, hbB, qB);
+                    const bop_t b_next = btab[(seg0 + tr + 1) * 64 + lane];
+                    const float k_next = ktab[(seg0 + tr + 1) * 16 + col];
+                    mfma_half(0, b_cur, hbA, qA);
                     look_half(0, hbA, qA, k_cur, tr);
-                    mfma_half(0, b_next, hbA, qA);      // (the last one computes a spare tile: unused)
-                    look_half(1, hbB, qB, k_cur, tr);
-                    b_cur = b_next; b_next = b_nn; k_cur = k_next; k_next = k_nn;
+                    mfma_half(1, b_cur, hbA, qA);
+                    look_half(1, hbA, qA, k_cur, tr);
+                    b_cur = b_next; k_cur = k_next;
                 }
                 __builtin_amdgcn_wave_barrier();
                 RT_STAMP(6);
@@ -414,6 +418,12 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
             }
         }
 
+        {   // fold this bounce's counts into the wave totals (all lanes are here)
+            uint32_t pk = n_cand | (n_roots << 16);                 // < 65536 each per lane per bounce
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o_ = (uint32_t)__shfl_xor((int)pk, sh); pk = ((pk & 0xFFFFu) + (o_ & 0xFFFFu)) | (((pk >> 16) + (o_ >> 16)) << 16); }
+            tot_cand += pk & 0xFFFFu; tot_roots += pk >> 16;
+        }
         RT_STAMP(3);
         // ---- (e) shade: main.rs:44-56 + materials.rs ----------------------------
         if (alive) {
@@ -498,11 +508,10 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const KParams P)
     if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(P.stats + 8 + k, ph[k]);
 #endif
     {
-        unsigned long long ns = n_samples, nc = n_cand, nr = n_roots;
+        unsigned long long ns = n_samples;
+        const unsigned long long nc = tot_cand, nr = tot_roots;
 #pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) {
-            ns += __shfl_xor(ns, sh); nc += __shfl_xor(nc, sh); nr += __shfl_xor(nr, sh);
-        }
+        for (int sh = 32; sh >= 1; sh >>= 1) ns += __shfl_xor(ns, sh);
         if (lane == 0) {
             atomicAdd(P.stats + 0, (unsigned long long)n_rays);
             atomicAdd(P.stats + 1, ns);
