@@ -64,7 +64,7 @@ constexpr int RT_KIND_LAMBERTIAN = 0, RT_KIND_METAL = 1, RT_KIND_DIALECTRIC = 2;
 constexpr int kBlock = 256;
 constexpr int kCandCap = 24;        // per-lane candidate slots
 constexpr int kScanUnroll = 8;      // spheres per overflow check
-constexpr int kItemBlock = 128;     // work items a wave reserves per atomic (>= 64)
+constexpr int kItemBlock = 256;     // work items a wave reserves per atomic (>= 64)
 constexpr int kSegTiles = 36;       // matrix filter: tiles (of 16 spheres) per candidate-bitmap segment
 
 __device__ __forceinline__ D3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
