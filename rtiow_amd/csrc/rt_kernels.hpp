@@ -419,10 +419,10 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
         }
 
         {   // fold this bounce's counts into the wave totals (all lanes are here)
-            uint32_t pk = n_cand | (n_roots << 16);                 // < 65536 each per lane per bounce
+            unsigned long long pk = (unsigned long long)n_cand | ((unsigned long long)n_roots << 32);
 #pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o_ = (uint32_t)__shfl_xor((int)pk, sh); pk = ((pk & 0xFFFFu) + (o_ & 0xFFFFu)) | (((pk >> 16) + (o_ >> 16)) << 16); }
-            tot_cand += pk & 0xFFFFu; tot_roots += pk >> 16;
+            for (int sh = 32; sh >= 1; sh >>= 1) pk += __shfl_xor(pk, sh);      // both halves < 2^32: no carry across
+            tot_cand += pk & 0xFFFFFFFFull; tot_roots += pk >> 32;
         }
         RT_STAMP(3);
         // ---- (e) shade: main.rs:44-56 + materials.rs ----------------------------
