@@ -166,3 +166,44 @@ def test_errors(renderer, book1_flat):
         fresh.close()
     with pytest.raises(rt.RtiowHipError, match="device_id"):
         rt.Renderer(99)
+
+
+def _random_world(rng, n, spread, rmin, rmax, ground=True):
+    w = rt.HittableList()
+    if ground:
+        w.push(rt.Sphere(rt.Point3(0, -1000, 0), 1000, rt.Lambertian(rt.Color(0.5, 0.5, 0.5))))
+    for _ in range(n):
+        c = rng.uniform(-spread, spread, 3)
+        c[1] = abs(c[1]) * 0.3
+        r = float(rng.uniform(rmin, rmax))
+        k = rng.integers(0, 3)
+        if k == 0:
+            m = rt.Lambertian(rng.uniform(0.05, 0.95, 3))
+        elif k == 1:
+            m = rt.Metal(rng.uniform(0.5, 1.0, 3), float(rng.uniform(0.0, 0.5)))
+        else:
+            m = rt.Dialectric(float(rng.uniform(1.2, 2.4)))
+        w.push(rt.Sphere(c, r, m))
+    return w.flatten()
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_random_scenes_and_cameras_bit_exact(renderer, oracle_mod, case):
+    """Scenes the filter constants were NOT tuned on: overlapping spheres of mixed sizes, far-away
+    clusters (large |c|), cameras inside the cloud, wide and narrow fields of view, odd image sizes
+    (ragged row tiles), several bitmap words per ray."""
+    rng = np.random.default_rng(1000 + case)
+    n = int(rng.integers(3, 700))
+    spread = float(10.0 ** rng.uniform(0.3, 2.5))
+    flat = _random_world(rng, n, spread, 0.05 * spread / 10, 0.6 * spread / 10, ground=bool(case % 2))
+    w, h, spp = int(rng.integers(17, 90)), int(rng.integers(9, 60)), int(rng.integers(1, 6))
+    look_from = rng.uniform(-spread, spread, 3); look_from[1] = abs(look_from[1]) * 0.3 + 0.5
+    look_at = rng.uniform(-spread, spread, 3) * 0.3
+    cam = rt.Camera(look_from, look_at, rt.Vec3(0, 1, 0), float(rng.uniform(10, 100)), w / h,
+                    float(rng.uniform(0.0, 0.3)), float(np.linalg.norm(look_from - look_at)))
+    seed = int(rng.integers(1, 2 ** 62))
+    renderer.upload_scene(flat)
+    sm, fix, st = renderer.render(cam, rt.make_params(w, h, spp, seed=seed, tile_rows=int(rng.integers(1, 9))))
+    fb, sb, stb = oracle_mod.render_b(oracle_mod.camera_from_host(cam), flat, oracle_mod.make_params(w, h, spp, seed=seed))
+    assert np.array_equal(fix, fb), case
+    assert st["rays_traced"] == stb["rays_traced"]
