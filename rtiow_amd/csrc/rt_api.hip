@@ -51,7 +51,7 @@ struct rt_context {
     int cu_count = 0;
     float *d_filt = nullptr;       // [n][4] f32 filter records
     double *d_geo = nullptr;       // [n][4] exact geometry
-    double *d_mat = nullptr;       // [n][6] exact materials
+    double *d_mat = nullptr;       // [n][kMatStride] exact materials
     float *d_bmat = nullptr;       // [tiles][64] MFMA B operand of the filter
     float *d_kpt = nullptr;        // [tiles][16] K' per sphere
     uint4 *d_bmat16 = nullptr;     // [tiles][64] bf16x3 B operand
@@ -228,7 +228,7 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
     ctx->n_spheres = -1;
     const size_t cnt = (size_t)(n > 0 ? n : 1);
     std::vector<float> filt(cnt * 4, 0.0f);
-    std::vector<double> geo(cnt * 4, 0.0), mat(cnt * 6, 0.0);
+    std::vector<double> geo(cnt * 4, 0.0), mat(cnt * rt::kMatStride, 0.0);
     const double KU = (double)rt::kFilterKU;
     const double kappa = KU / (1.0 - KU);
     for (int i = 0; i < n; ++i) {
@@ -238,10 +238,19 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
         const double r2 = s.radius * s.radius;
         geo[4 * i + 0] = s.center[0]; geo[4 * i + 1] = s.center[1]; geo[4 * i + 2] = s.center[2];
         geo[4 * i + 3] = r2;
-        mat[6 * i + 0] = 1.0 / s.radius;
-        mat[6 * i + 1] = s.param;
-        mat[6 * i + 2] = s.albedo[0]; mat[6 * i + 3] = s.albedo[1]; mat[6 * i + 4] = s.albedo[2];
-        mat[6 * i + 5] = (double)s.kind;
+        double *m = &mat[(size_t)rt::kMatStride * i];
+        m[0] = 1.0 / s.radius;
+        m[1] = s.param;
+        m[2] = s.albedo[0]; m[3] = s.albedo[1]; m[4] = s.albedo[2];
+        m[5] = (double)s.kind;
+        if (s.kind == RT_DIALECTRIC) {
+            // materials.rs:84-87 `1.0/self.ir` and :79 `((1-ri)/(1+ri)).powi(2)` for the two ratios a
+            // Dialectric can see (front: 1/ir, back: ir): the reference's own f64 operations, hoisted
+            m[6] = 1.0 / s.param;
+            double r0 = (1.0 - m[6]) / (1.0 + m[6]); m[7] = r0 * r0;
+            r0 = (1.0 - s.param) / (1.0 + s.param); m[8] = r0 * r0;
+            m[2] = 1.0; m[3] = 1.0; m[4] = 1.0;                                  // attenuation (1,1,1), :103
+        }
         // filter record (rt_device.hpp): centre rounded to f32 and
         // K' = |c|^2 (1-kappa) - r^2 (1+2 kappa), rounded DOWN (a smaller K' keeps more)
         const double c2 = s.center[0] * s.center[0] + s.center[1] * s.center[1] + s.center[2] * s.center[2];
@@ -327,10 +336,10 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
     RT_HIP(hipMemcpy(ctx->d_kpt, kpt.data(), tcnt * 16 * sizeof(float), hipMemcpyHostToDevice));
     RT_HIP(hipMalloc((void **)&ctx->d_filt, cnt * 4 * sizeof(float)));
     RT_HIP(hipMalloc((void **)&ctx->d_geo, cnt * 4 * sizeof(double)));
-    RT_HIP(hipMalloc((void **)&ctx->d_mat, cnt * 6 * sizeof(double)));
+    RT_HIP(hipMalloc((void **)&ctx->d_mat, cnt * rt::kMatStride * sizeof(double)));
     RT_HIP(hipMemcpy(ctx->d_filt, filt.data(), cnt * 4 * sizeof(float), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->d_geo, geo.data(), cnt * 4 * sizeof(double), hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(ctx->d_mat, mat.data(), cnt * 6 * sizeof(double), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_mat, mat.data(), cnt * rt::kMatStride * sizeof(double), hipMemcpyHostToDevice));
     ctx->n_spheres = n;
     return RT_OK;
 }

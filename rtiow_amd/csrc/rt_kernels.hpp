@@ -54,7 +54,7 @@ struct KParams {
     int32_t n_always;          // spheres that skip the filter and are always tested exactly
     int32_t always_idx[8];
     const double *geo;         // [n][4]  exact (cx, cy, cz, r*r)
-    const double *mat;         // [n][6]  exact (1/r, param, albedo rgb, kind)
+    const double *mat;         // [n][10] exact (1/r, param, albedo rgb, kind, 1/param, r0(1/ir), r0(ir), -)
     unsigned long long *fix;   // [rows][width][3] exact sums
     unsigned int *queue;       // work counter
     unsigned long long *stats; // [0] rays [1] samples [2] candidates [3] exact roots
@@ -65,6 +65,7 @@ constexpr int kBlock = 256;
 constexpr int kCandCap = 24;        // per-lane candidate slots
 constexpr int kScanUnroll = 8;      // spheres per overflow check
 constexpr int kItemBlock = 256;     // work items a wave reserves per atomic (>= 64)
+constexpr int kMatStride = 10;      // doubles per material record
 constexpr int kSegTiles = 36;       // matrix filter: tiles (of 16 spheres) per candidate-bitmap segment
 
 __device__ __forceinline__ D3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
@@ -429,58 +430,79 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
         if (alive) {
             bool done = false;
             D3 L = mk(0.0, 0.0, 0.0);
-            if (hit < 0) {
-                const D3 ud = unit_vector(d);                                   // main.rs:54
-                const double t = 0.5 * (ud.y + 1.0);                            // main.rs:55
-                const D3 sky = mk(1.0, 1.0, 1.0) * (1.0 - t) + mk(0.5, 0.7, 1.0) * t;
-                L = thr * sky;                                                  // contract C3
-                done = true;
-            } else {
+            const bool is_hit = hit >= 0;
+            int kind = -1;
+            bool front = false;
+            D3 p = o, nrm = mk(0.0, 0.0, 0.0), sp = mk(0.0, 0.0, 0.0), albedo = mk(1.0, 1.0, 1.0);
+            double param = 0.0, inv_param = 0.0, r0_front = 0.0, r0_back = 0.0;
+            if (is_hit) {
+                const double *mrec = mat + kMatStride * (size_t)hit;
                 const double4 g = *reinterpret_cast<const double4 *>(geo + 4 * (size_t)hit);
-                const double2 mA = *reinterpret_cast<const double2 *>(mat + 6 * (size_t)hit);      // 1/r, param
-                const double2 mB = *reinterpret_cast<const double2 *>(mat + 6 * (size_t)hit + 2);  // albedo r,g
-                const double2 mC = *reinterpret_cast<const double2 *>(mat + 6 * (size_t)hit + 4);  // albedo b, kind
-                const int kind = (int)mC.y;
+                const double2 mA = *reinterpret_cast<const double2 *>(mrec);          // 1/r, param
+                const double2 mB = *reinterpret_cast<const double2 *>(mrec + 2);      // albedo r, g
+                const double2 mC = *reinterpret_cast<const double2 *>(mrec + 4);      // albedo b, kind
+                kind = (int)mC.y;
+                param = mA.y;
+                albedo = mk(mB.x, mB.y, mC.x);
                 // sphere.rs:36-37 + mod.rs:20-30
-                const D3 p = o + d * closest;                                   // ray.rs:15-17
-                const D3 outward = (p - mk(g.x, g.y, g.z)) * mA.x;              // / radius = * (1/radius)
-                const bool front = dot(d, outward) < 0.0;
-                const D3 nrm = front ? outward : (mk(0.0, 0.0, 0.0) - outward);
-                D3 ndir = mk(0.0, 0.0, 0.0);
+                p = o + d * closest;                                             // ray.rs:15-17
+                const D3 outward = (p - mk(g.x, g.y, g.z)) * mA.x;               // / radius = * (1/radius)
+                front = dot(d, outward) < 0.0;
+                nrm = front ? outward : (mk(0.0, 0.0, 0.0) - outward);
                 if (kind != RT_KIND_DIALECTRIC) {
-                    D3 sp;
                     do {                                                         // vec3.rs:37-45
                         const U4 w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
                         ev++;
                         sp = mk(u11(w.x), u11(w.y), u11(w.z));
                     } while (!(length_squared(sp) < 1.0));
-                    if (kind == RT_KIND_LAMBERTIAN) {                            // materials.rs:21-31
-                        ndir = nrm + unit_vector(sp);
-                        const double eps = 1e-8;
-                        if (__builtin_fabs(ndir.x) < eps && __builtin_fabs(ndir.y) < eps &&
-                            __builtin_fabs(ndir.z) < eps)
-                            ndir = nrm;
-                    } else {                                                     // materials.rs:48-62
-                        const D3 reflected = unit_vector(reflect(d, nrm));
-                        ndir = reflected + sp * mA.y;
-                        if (dot(ndir, nrm) <= 0.0) done = true;                  // absorbed: L = 0
-                    }
-                    thr = thr * mk(mB.x, mB.y, mC.x);
+                } else {
+                    const double2 mD = *reinterpret_cast<const double2 *>(mrec + 6);  // 1/ir, r0(1/ir)
+                    const double2 mE = *reinterpret_cast<const double2 *>(mrec + 8);  // r0(ir), -
+                    inv_param = mD.x; r0_front = mD.y; r0_back = mE.x;
+                }
+            }
+            // Every branch normalises exactly one vector (vec3.rs:107-109: v * (1/sqrt(v.v))): the
+            // sky and Dialectric take unit(d), Lambertian unit(sample), Metal unit(reflect(d,n)).
+            // One shared f64 sqrt + divide for the whole wave instead of one per branch.
+            D3 V = d;
+            if (kind == RT_KIND_LAMBERTIAN) V = sp;
+            if (kind == RT_KIND_METAL) V = reflect(d, nrm);
+            const D3 uV = unit_vector(V);
+            if (!is_hit) {
+                const double t = 0.5 * (uV.y + 1.0);                             // main.rs:54-55
+                const D3 sky = mk(1.0, 1.0, 1.0) * (1.0 - t) + mk(0.5, 0.7, 1.0) * t;
+                L = thr * sky;                                                   // contract C3
+                done = true;
+            } else {
+                D3 ndir;
+                if (kind == RT_KIND_LAMBERTIAN) {                                // materials.rs:21-31
+                    ndir = nrm + uV;
+                    const double eps = 1e-8;
+                    if (__builtin_fabs(ndir.x) < eps && __builtin_fabs(ndir.y) < eps &&
+                        __builtin_fabs(ndir.z) < eps)
+                        ndir = nrm;
+                } else if (kind == RT_KIND_METAL) {                              // materials.rs:48-62
+                    ndir = uV + sp * param;
+                    if (dot(ndir, nrm) <= 0.0) done = true;                      // absorbed: L = 0
                 } else {                                                         // materials.rs:76-105
-                    const double ratio = front ? 1.0 / mA.y : mA.y;
-                    const D3 ud = unit_vector(d);
-                    const double cos_theta = min_1(-dot(ud, nrm));
+                    // 1.0/ir and ((1-ri)/(1+ri))^2 for both ratios are per-sphere constants: the same
+                    // f64 operations, done once on the host (rt_api.hip)
+                    const double ratio = front ? inv_param : param;
+                    const double cos_theta = min_1(-dot(uV, nrm));
                     const double sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
                     bool do_refract = false;
                     if (ratio * sin_theta <= 1.0) {                              // && short-circuit
-                        const double refl = reflectance(cos_theta, ratio);
+                        const double r0 = front ? r0_front : r0_back;            // materials.rs:79
+                        const double x = 1.0 - cos_theta;
+                        const double x2 = x * x;
+                        const double refl = r0 + (1.0 - r0) * ((x2 * x2) * x);   // materials.rs:80
                         const U4 w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
                         ev++;
                         do_refract = refl <= u01(w.x);
                     }
-                    ndir = do_refract ? refract(ud, nrm, ratio) : reflect(ud, nrm);
-                    thr = thr * mk(1.0, 1.0, 1.0);
+                    ndir = do_refract ? refract(uV, nrm, ratio) : reflect(uV, nrm);
                 }
+                thr = thr * albedo;                                              // (1,1,1) for Dialectric
                 o = p;
                 d = ndir;
                 depth -= 1;

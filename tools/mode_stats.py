@@ -8,7 +8,7 @@ import rtiow_amd as rt
 flat = rt.random_scene(1).flatten()
 for mode in [int(x) for x in os.environ.get('MODES', '3,2,1').split(',')]:
     for chunk in [int(x) for x in os.environ.get('CHUNKS', '4').split(',')]:
-      for ib in [int(x) for x in os.environ.get('IBS', '128').split(',')]:
+      for ib in [int(x) for x in os.environ.get('IBS', '256').split(',')]:
         os.environ['RTIOW_ITEM_BLOCK'] = str(ib)
         os.environ["RTIOW_SCAN_MODE"] = str(mode); os.environ["RTIOW_CHUNK"] = str(chunk)
         r = rt.Renderer(0); r.upload_scene(flat)
