@@ -81,7 +81,8 @@ def main():
     ap.add_argument("--width", type=int, default=1200)
     ap.add_argument("--height", type=int, default=675)
     ap.add_argument("--spp", type=int, default=100, help="samples per pixel PER GPU-share (frame spp = spp x N)")
-    ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--tile-rows", type=int, default=1,
+                    help="rows per shard tile; 1 balances the ranks to within one row of each other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 logic check on a 1-GPU box: every rank renders on cuda:0 and the gather runs "
