@@ -3,7 +3,7 @@
 // the image crate's PNG; no preview window).
 //
 //   rtiow_render [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--scene-seed S]
-//                [--grid LO HI] [--device K] [--out image.ppm] [--dump-scene scene.bin]
+//                [--grid LO HI] [--device K] [--out image.ppm] [--dump-scene scene.bin] [--scene scene.bin]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,7 +21,7 @@ int main(int argc, char **argv)
 {
     int width = 400, height = 225, spp = 10, depth = 50, device = 0, lo = -11, hi = 11;
     unsigned long long seed = 1, scene_seed = 1;
-    std::string out = "image.ppm", dump;
+    std::string out = "image.ppm", dump, scene_file;
     for (int i = 1; i < argc; ++i) {
         auto arg = [&](const char *n) { return !std::strcmp(argv[i], n) && i + 1 < argc; };
         if (arg("--width")) width = std::atoi(argv[++i]);
@@ -33,11 +33,23 @@ int main(int argc, char **argv)
         else if (arg("--device")) device = std::atoi(argv[++i]);
         else if (arg("--out")) out = argv[++i];
         else if (arg("--dump-scene")) dump = argv[++i];
+        else if (arg("--scene")) scene_file = argv[++i];
         else if (!std::strcmp(argv[i], "--grid") && i + 2 < argc) { lo = std::atoi(argv[++i]); hi = std::atoi(argv[++i]); }
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     const rtiow::HittableList world = rtiow::random_scene(scene_seed, lo, hi);      // main.rs:106
-    const std::vector<rt_sphere> flat = world.flatten();
+    std::vector<rt_sphere> flat = world.flatten();
+    if (!scene_file.empty()) {                   // a flat scene file instead of random_scene()
+        FILE *f = std::fopen(scene_file.c_str(), "rb");
+        if (!f) { std::perror(scene_file.c_str()); return 1; }
+        std::fseek(f, 0, SEEK_END);
+        const long bytes = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        if (bytes < 0 || bytes % (long)sizeof(rt_sphere)) { std::fprintf(stderr, "%s: not a whole number of 72-byte records\n", scene_file.c_str()); return 1; }
+        flat.resize((size_t)bytes / sizeof(rt_sphere));
+        if (std::fread(flat.data(), sizeof(rt_sphere), flat.size(), f) != flat.size()) { std::perror(scene_file.c_str()); return 1; }
+        std::fclose(f);
+    }
     if (!dump.empty()) {                         // the flat scene file: count + 72-byte records
         FILE *f = std::fopen(dump.c_str(), "wb");
         if (!f) { std::perror(dump.c_str()); return 1; }

@@ -22,3 +22,18 @@ def read_ppm(path):
     assert parts[0] == b"P6"
     w, h = (int(x) for x in parts[1].split())
     return np.frombuffer(parts[3], dtype=np.uint8).reshape(h, w, 3)
+
+
+# ---- resumable accumulation -----------------------------------------------
+# The exact u64 sums are additive over sample ranges (counter-based RNG + integer sums), so a
+# checkpoint is just the sums plus how many samples they hold; resuming = rendering the next
+# sample range (rt_params.sample_begin) and adding.
+
+def save_checkpoint(path, fix, spp_done, seed):
+    np.savez_compressed(path, fix=np.ascontiguousarray(fix, dtype=np.uint64),
+                        spp_done=np.int64(spp_done), seed=np.uint64(seed))
+
+
+def load_checkpoint(path):
+    z = np.load(path, allow_pickle=False)
+    return z["fix"], int(z["spp_done"]), int(z["seed"])

@@ -180,3 +180,23 @@ def book1_camera(width, height):
     """main.rs:108-118 with ASPECT_RATIO = width/height (a runtime value here)."""
     return Camera(Point3(13, 2, 3), Point3(0, 0, 0), Vec3(0, 1, 0), 20.0,
                   float(width) / float(height), 0.1, 10.0)
+
+
+# ---- flat scene file: the step immediately before the path (SURVEY 8f-1) ---------------
+# Raw little-endian rt_sphere records (72 bytes each, include/rtiow_hip.h), list order kept.
+# host/rtiow_render --dump-scene writes the same bytes.
+
+def save_scene(path, world):
+    flat = world.flatten() if hasattr(world, "flatten") and not isinstance(world, np.ndarray) else world
+    np.ascontiguousarray(flat, dtype=SPHERE_DTYPE).tofile(path)
+
+
+def load_scene(path):
+    import os
+    size = os.path.getsize(path)
+    if size % SPHERE_DTYPE.itemsize:
+        raise ValueError(f"{path}: {size} bytes is not a whole number of 72-byte sphere records")
+    flat = np.fromfile(path, dtype=SPHERE_DTYPE)
+    if ((flat["kind"] < 0) | (flat["kind"] > 2)).any():
+        raise ValueError(f"{path}: unknown material kind")
+    return flat

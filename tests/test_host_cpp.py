@@ -37,3 +37,16 @@ def test_cpp_cli_renders_the_same_image(tmp_path, renderer, book1_flat):
     _, fix, _ = renderer.render(rt.book1_camera(160, 90), rt.make_params(160, 90, 6))
     want = renderer.resolve_rgba8(fix, 6, flip=True)[:, :, :3]
     assert np.array_equal(rt.read_ppm(out), want)
+
+
+@pytest.mark.gpu
+def test_cpp_cli_reads_a_scene_file(tmp_path, renderer):
+    world = rt.random_scene(5)
+    path = str(tmp_path / "s.bin")
+    rt.save_scene(path, world)
+    out = str(tmp_path / "image.ppm")
+    subprocess.run([_cli(), "--scene", path, "--width", "96", "--height", "54", "--spp", "3", "--out", out],
+                   check=True, capture_output=True)
+    renderer.upload_scene(world)
+    _, fix, _ = renderer.render(rt.book1_camera(96, 54), rt.make_params(96, 54, 3))
+    assert np.array_equal(rt.read_ppm(out), renderer.resolve_rgba8(fix, 3, flip=True)[:, :, :3])

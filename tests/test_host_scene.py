@@ -86,3 +86,22 @@ def test_ppm_roundtrip(tmp_path):
     path = tmp_path / "x.ppm"
     rt.write_ppm(str(path), rgba)
     assert np.array_equal(rt.read_ppm(str(path)), rgba[:, :, :3])
+
+
+def test_scene_file_roundtrip(tmp_path, book1_flat):
+    path = str(tmp_path / "scene.bin")
+    rt.save_scene(path, rt.random_scene(1))
+    got = rt.load_scene(path)
+    assert got.tobytes() == book1_flat.tobytes()
+    with open(path, "ab") as f:
+        f.write(b"\0" * 5)
+    with pytest.raises(ValueError):
+        rt.load_scene(path)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    fix = (np.arange(4 * 5 * 3, dtype=np.uint64) * np.uint64(1 << 33)).reshape(4, 5, 3)
+    path = str(tmp_path / "ck.npz")
+    rt.save_checkpoint(path, fix, 37, 0xDEADBEEF12345678)
+    f2, spp, seed = rt.load_checkpoint(path)
+    assert np.array_equal(f2, fix) and spp == 37 and seed == 0xDEADBEEF12345678
