@@ -1,0 +1,47 @@
+"""Randomised GPU-vs-oracle parity soak (development tool): many random scenes, cameras, image
+sizes and seeds; every frame must equal Oracle B bit for bit.  Usage: fuzz_parity.py [cases] [seed0]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import oracle
+import rtiow_amd as rt
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+r = rt.Renderer(0)
+bad = 0
+t0 = time.time()
+tot_rays = 0
+for case in range(cases):
+    rng = np.random.default_rng(seed0 * 100003 + case)
+    n = int(rng.integers(1, 1200))
+    spread = float(10.0 ** rng.uniform(0.0, 3.0))
+    w = rt.HittableList()
+    if rng.random() < 0.6:
+        w.push(rt.Sphere(rt.Point3(0, -1000 * spread / 10, 0), 1000 * spread / 10, rt.Lambertian(rt.Color(0.5, 0.5, 0.5))))
+    rscale = spread / 10 * float(10.0 ** rng.uniform(-1.5, 0.3))
+    for _ in range(n):
+        c = rng.uniform(-spread, spread, 3); c[1] = abs(c[1]) * rng.uniform(0.0, 0.5)
+        rad = float(rng.uniform(0.2, 1.5)) * rscale
+        k = rng.integers(0, 3)
+        m = (rt.Lambertian(rng.uniform(0.05, 0.95, 3)) if k == 0 else
+             rt.Metal(rng.uniform(0.5, 1.0, 3), float(rng.uniform(0.0, 0.5))) if k == 1 else
+             rt.Dialectric(float(rng.uniform(1.1, 2.5))))
+        w.push(rt.Sphere(c, rad, m))
+    flat = w.flatten()
+    W, H, spp = int(rng.integers(8, 64)), int(rng.integers(6, 48)), int(rng.integers(1, 5))
+    lf = rng.uniform(-spread, spread, 3); lf[1] = abs(lf[1]) * 0.3 + 0.3 * spread / 10
+    la = rng.uniform(-spread, spread, 3) * 0.3
+    cam = rt.Camera(lf, la, rt.Vec3(0, 1, 0), float(rng.uniform(5, 120)), W / H, float(rng.uniform(0.0, 0.5)) * spread / 10,
+                    float(np.linalg.norm(lf - la)) + 1e-3)
+    seed = int(rng.integers(1, 2 ** 62))
+    r.upload_scene(flat)
+    sm, fix, st = r.render(cam, rt.make_params(W, H, spp, seed=seed, tile_rows=int(rng.integers(1, 9))))
+    fb, sb, stb = oracle.render_b(oracle.camera_from_host(cam), flat, oracle.make_params(W, H, spp, seed=seed))
+    ok = np.array_equal(fix, fb) and st["rays_traced"] == stb["rays_traced"]
+    tot_rays += st["rays_traced"]
+    if not ok:
+        bad += 1
+        print(f"MISMATCH case {case}: n={len(flat)} {W}x{H}x{spp} spread={spread:.2f} diff px={int(np.count_nonzero((fix != fb).any(2)))}", flush=True)
+print(f"{cases} cases, {bad} mismatches, {tot_rays} rays, mode {os.environ.get('RTIOW_SCAN_MODE', '3 (default)')}, {time.time() - t0:.1f} s", flush=True)
+sys.exit(1 if bad else 0)
