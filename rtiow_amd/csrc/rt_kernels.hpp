@@ -7,18 +7,18 @@
 //     LANE owns one path at a time and never waits for its neighbours -- when
 //     its path ends it immediately starts its next pixel-sample ("path
 //     regeneration"), so the sphere scan always runs with full waves;
-//   * work = items (pixel, chunk of <= `chunk` consecutive samples), handed
-//     out by ONE device-wide counter; a wave fetches for all its idle lanes
-//     with a single returning atomic (__ballot + popcount + prefix rank);
-//   * the sphere scan (HittableList::hit, mod.rs:54-70) walks the list in
-//     order with a WAVE-UNIFORM index, so the 16-byte f32 filter records
-//     arrive through the scalar data path (s_load -> SGPRs) and cost no
-//     vector-memory or LDS bandwidth: 7 f32 FMAs + 1 compare + 1 branch per test;
-//   * the scan itself decides nothing: it is a conservative f32 FILTER
-//     (rt_device.hpp).  Spheres it cannot rule out are appended to a short
-//     per-lane list in LDS and go through the reference's exact f64 test
-//     (sphere.rs:16-34) afterwards, in list order -- so every hit decision and
-//     every shading value is the reference's own f64 arithmetic;
+//   * work = items (pixel, chunk of <= `chunk` consecutive samples); a wave
+//     reserves a block of items with ONE returning atomic on a device-wide
+//     counter and deals them to its idle lanes (__ballot + popcount + prefix rank);
+//   * the sphere scan (HittableList::hit, mod.rs:54-70) decides nothing: it is a
+//     conservative FILTER (rt_device.hpp) -- it may send a sphere to the exact
+//     test needlessly, never drop one the reference would hit.  The shipped form
+//     (MODE 3) evaluates it on the bf16 matrix pipe, 16 rays x 16 spheres per
+//     instruction; MODE 1 (VALU + scalar loads) and MODE 2 (f32 matrix pipe) are
+//     kept as cross-checks, MODE 0 has no filter at all;
+//   * spheres the filter keeps are marked in per-ray LDS bitmaps and then go
+//     through the reference's exact f64 test (sphere.rs:16-34), so every hit
+//     decision and every shading value is the reference's own f64 arithmetic;
 //   * per-lane radiance sums are exact u64 fixed point (contract C5) and are
 //     added to the frame buffer with 64-bit atomics once per item.
 #pragma once
@@ -62,8 +62,8 @@ struct KParams {
 
 constexpr int RT_KIND_LAMBERTIAN = 0, RT_KIND_METAL = 1, RT_KIND_DIALECTRIC = 2;
 constexpr int kBlock = 256;
-constexpr int kCandCap = 24;        // per-lane candidate slots
-constexpr int kScanUnroll = 8;      // spheres per overflow check
+constexpr int kCandCap = 24;        // MODE 1: per-lane candidate slots
+constexpr int kScanUnroll = 8;      // MODE 1: spheres per scalar-load batch / overflow check
 constexpr int kItemBlock = 256;     // work items a wave reserves per atomic (>= 64)
 constexpr int kMatStride = 10;      // doubles per material record
 constexpr int kSegTiles = 36;       // matrix filter: tiles (of 16 spheres) per candidate-bitmap segment
@@ -89,8 +89,7 @@ template <int MODE>
 // is latency-bound, and the 4th wave is worth more than the few cold values it spills
 __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void render_kernel(const KParams P)
 {
-    constexpr bool FILTERED = (MODE != 0);
-    __shared__ uint16_t cand[FILTERED ? kCandCap : 1][kBlock];
+    __shared__ uint16_t cand[MODE == 1 ? kCandCap : 1][kBlock];     // MODE 1: per-lane candidate lists
     constexpr bool MATRIX = (MODE == 2 || MODE == 3);
     __shared__ float s_rayop[MATRIX ? kBlock / 64 : 1][MATRIX ? 8 : 1][MATRIX ? kRowPad : 1];
     // per ray, one bit per sphere of the current segment (kSegTiles tiles): set by whichever lane
