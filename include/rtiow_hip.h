@@ -107,13 +107,14 @@ typedef struct {
 
 #define RT_FLAG_ACCUMULATE 0x1u  /* rt_render_device: add to d_fix instead of overwriting it */
 #define RT_FLAG_NO_FILTER  0x2u  /* validation: send EVERY sphere to the exact f64 test     */
+#define RT_FLAG_DIAG_STATS 0x4u  /* also fill rt_stats.candidates / exact_roots (~2.5 % slower) */
 
 typedef struct {
     uint64_t samples;            /* pixel-samples finished                          */
     uint64_t rays_traced;        /* HittableList::hit calls (mod.rs:56)             */
     uint64_t sphere_tests;       /* rays_traced * n_spheres (sphere.rs:16 calls)    */
-    uint64_t candidates;         /* tests the f32 filter passed on to the f64 test  */
-    uint64_t exact_roots;        /* f64 tests that reached the sqrt (sphere.rs:26)  */
+    uint64_t candidates;         /* tests the filter passed on to the f64 test (RT_FLAG_DIAG_STATS, else 0) */
+    uint64_t exact_roots;        /* f64 tests that reached the sqrt, sphere.rs:26   (RT_FLAG_DIAG_STATS, else 0) */
     float    kernel_ms;          /* render kernel, HIP events on its stream         */
     int32_t  n_spheres;
     int32_t  grid_blocks, block_threads;

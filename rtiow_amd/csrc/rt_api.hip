@@ -118,13 +118,13 @@ int ensure(void **ptr, size_t *have, size_t need)
     return RT_OK;
 }
 
-template <int MODE>
+template <int MODE, bool DIAG>
 int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, int *grid_out)
 {
     int per_cu = ctx->blocks_per_cu;
     if (per_cu <= 0) {
         int occ = 0;
-        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rt::render_kernel<MODE>, rt::kBlock, 0));
+        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rt::render_kernel<MODE, DIAG>, rt::kBlock, 0));
         per_cu = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
     }
     // persistent grid, but never more lanes than there are work items
@@ -134,7 +134,7 @@ int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, in
     if (grid < 1) grid = 1;
     *grid_out = (int)grid;
     RT_HIP(hipEventRecord(ctx->ev0, stream));
-    hipLaunchKernelGGL(rt::render_kernel<MODE>, dim3((unsigned)grid), dim3(rt::kBlock), 0, stream, kp);
+    hipLaunchKernelGGL((rt::render_kernel<MODE, DIAG>), dim3((unsigned)grid), dim3(rt::kBlock), 0, stream, kp);
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(ctx->ev1, stream));
     return RT_OK;
@@ -424,10 +424,18 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     }
 
     int grid = 0;
-    if (p->flags & RT_FLAG_NO_FILTER) rc = launch_render<0>(ctx, kp, stream, &grid);
-    else if (ctx->scan_mode == 1) rc = launch_render<1>(ctx, kp, stream, &grid);
-    else if (ctx->scan_mode == 2) rc = launch_render<2>(ctx, kp, stream, &grid);
-    else rc = launch_render<3>(ctx, kp, stream, &grid);
+    const bool diag = (p->flags & RT_FLAG_DIAG_STATS) != 0;
+    const int mode = (p->flags & RT_FLAG_NO_FILTER) ? 0 : ctx->scan_mode;
+    switch (mode * 2 + (diag ? 1 : 0)) {
+    case 0: rc = launch_render<0, false>(ctx, kp, stream, &grid); break;
+    case 1: rc = launch_render<0, true>(ctx, kp, stream, &grid); break;
+    case 2: rc = launch_render<1, false>(ctx, kp, stream, &grid); break;
+    case 3: rc = launch_render<1, true>(ctx, kp, stream, &grid); break;
+    case 4: rc = launch_render<2, false>(ctx, kp, stream, &grid); break;
+    case 5: rc = launch_render<2, true>(ctx, kp, stream, &grid); break;
+    case 6: rc = launch_render<3, false>(ctx, kp, stream, &grid); break;
+    default: rc = launch_render<3, true>(ctx, kp, stream, &grid); break;
+    }
     if (rc) return rc;
     ctx->launched = true;
     ctx->last.grid_blocks = grid;

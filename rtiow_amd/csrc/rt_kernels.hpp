@@ -84,7 +84,9 @@ constexpr int kRowPad = 80;         // floats per row of the ray-operand transpo
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE>
+// DIAG: also count filter candidates and exact roots (rt_stats.candidates / exact_roots).  Off in
+// the shipped path: the two counters cost 8 spilled registers and 2.5 % of the frame time.
+template <int MODE, bool DIAG>
 // second launch bound = waves per SIMD the register allocator must leave room for: the bounce loop
 // is latency-bound, and the 4th wave is worth more than the few cold values it spills
 __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void render_kernel(const KParams P)
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
             // sphere lies behind the ray (half_b > 0): sqrt(disc) <= half_b, so the
             // reference's two range tests (sphere.rs:29-33) both fail.  Skip the sqrt.
             if (half_b > 0.0 && c > 0.0) return;
-            n_roots++;
+            if (DIAG) n_roots++;
             const double sqrtd = __builtin_sqrt(disc);
             // sphere.rs:28-34 + mod.rs:61-67, written so that the ORDER in which a ray's
             // candidates are visited does not matter: the reference keeps sphere idx iff
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
         auto test_list = [&](int cnt) {
             // trip count = longest list among the active lanes (exec-masked vote)
             for (int k = 0; __any(k < cnt); ++k) {
-                if (k < cnt) { n_cand++; exact_test((int)cand[k][tid]); }
+                if (k < cnt) { if (DIAG) n_cand++; exact_test((int)cand[k][tid]); }
             }
         };
 
@@ -322,9 +324,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
                 }
             };
             if (alive) {
-                for (int e = 0; e < P.n_always; ++e) { n_cand++; exact_test(P.always_idx[e]); }
+                for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e]); }
                 // outside the analysed range: everything is tested exactly
-                if (!f.sane) for (int i = 0; i < n; ++i) { n_cand++; exact_test(i); }
+                if (!f.sane) for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i); }
             }
             const int nt = P.n_tiles;                   // even; the tables hold nt + 2 tiles
             RT_STAMP(5);
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
                             }
                             const int bpos = __builtin_ctz(word);
                             word &= word - 1u;
-                            n_cand++;
+                            if (DIAG) n_cand++;
                             exact_test(wbase + bpos);
                         }
                     }
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
         RT_STAMP(2);
         if (alive && !MATRIX) {
             if (MODE == 0) {
-                for (int i = 0; i < n; ++i) { n_cand++; exact_test(i); }
+                for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i); }
             } else {
                 const RayFilter f = make_filter(o, d);
                 int cnt = 0;
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
             }
         }
 
-        {   // fold this bounce's counts into the wave totals (all lanes are here)
+        if (DIAG) {   // fold this bounce's counts into the wave totals (all lanes are here)
             unsigned long long pk = (unsigned long long)n_cand | ((unsigned long long)n_roots << 32);
 #pragma unroll
             for (int sh = 32; sh >= 1; sh >>= 1) pk += __shfl_xor(pk, sh);      // both halves < 2^32: no carry across

@@ -64,8 +64,10 @@ def test_rmse_vs_literal_oracle_a_and_identical_bytes(renderer, oracle_mod, book
 
 def test_filter_never_changes_a_result(renderer, oracle_mod, book1_flat):
     """RT_FLAG_NO_FILTER sends every sphere through the exact test: same bits, far more work."""
-    (sm, fix, st), (fb, _, _), _ = both(renderer, oracle_mod, book1_flat, 160, 90, 6)
-    (_, fix2, st2), _, _ = both(renderer, oracle_mod, book1_flat, 160, 90, 6, flags=rt.RT_FLAG_NO_FILTER)
+    (sm, fix, st), (fb, _, _), _ = both(renderer, oracle_mod, book1_flat, 160, 90, 6, flags=rt.RT_FLAG_DIAG_STATS)
+    (_, fix2, st2), _, _ = both(renderer, oracle_mod, book1_flat, 160, 90, 6, flags=rt.RT_FLAG_NO_FILTER | rt.RT_FLAG_DIAG_STATS)
+    (_, fix3, st3), _, _ = both(renderer, oracle_mod, book1_flat, 160, 90, 6)
+    assert np.array_equal(fix3, fix) and st3["candidates"] == 0 and st3["rays_traced"] == st["rays_traced"]
     assert np.array_equal(fix, fix2) and np.array_equal(fix, fb)
     assert st2["candidates"] == st2["sphere_tests"] and st["candidates"] < st["sphere_tests"] // 50
     assert st["exact_roots"] == st2["exact_roots"]
@@ -101,7 +103,7 @@ def hand_scene(spheres):
 
 def test_empty_scene_is_pure_sky(renderer, oracle_mod):
     flat = hand_scene([])
-    (sm, fix, st), (fb, _, _), _ = both(renderer, oracle_mod, flat, 40, 30, 3)
+    (sm, fix, st), (fb, _, _), _ = both(renderer, oracle_mod, flat, 40, 30, 3, flags=rt.RT_FLAG_DIAG_STATS)
     assert np.array_equal(fix, fb) and st["rays_traced"] == 40 * 30 * 3 and st["candidates"] == 0
 
 

@@ -132,19 +132,21 @@ def test_all_scan_filters_give_the_same_bits(book1_flat, cfg2):
     """The three filter implementations (VALU + scalar loads, f32 MFMA, bf16x3 MFMA) are three
     ways of discarding spheres the reference cannot hit: the frame must not depend on which runs."""
     w, h, spp, fix, st = cfg2
-    cands = {}
+    cands, roots = {}, set()
     for mode in ("1", "2", "3"):
         os.environ["RTIOW_SCAN_MODE"] = mode
         try:
             r = rt.Renderer(0)
             r.upload_scene(book1_flat)
-            _, got, st2 = r.render(rt.book1_camera(w, h), rt.make_params(w, h, spp))
+            _, got, st2 = r.render(rt.book1_camera(w, h), rt.make_params(w, h, spp, flags=rt.RT_FLAG_DIAG_STATS))
             r.close()
         finally:
             os.environ.pop("RTIOW_SCAN_MODE")
         assert np.array_equal(got, fix), mode
-        assert st2["rays_traced"] == st["rays_traced"] and st2["exact_roots"] == st["exact_roots"]
+        assert st2["rays_traced"] == st["rays_traced"]
+        roots.add(st2["exact_roots"])
         cands[mode] = st2["candidates"]
+    assert len(roots) == 1                                  # the exact path sees the same real hits
     assert cands["1"] <= cands["2"] * 1.2 and cands["2"] <= cands["3"] * 1.01   # looser KU keeps more
 
 

@@ -13,6 +13,6 @@ for mode in [int(x) for x in os.environ.get('MODES', '3,2,1').split(',')]:
         os.environ["RTIOW_SCAN_MODE"] = str(mode); os.environ["RTIOW_CHUNK"] = str(chunk)
         r = rt.Renderer(0); r.upload_scene(flat)
         for _ in range(2):
-            sm, fix, st = r.render(rt.book1_camera(1200, 675), rt.make_params(1200, 675, 100), want_fix=False)
+            sm, fix, st = r.render(rt.book1_camera(1200, 675), rt.make_params(1200, 675, 100, flags=rt.RT_FLAG_DIAG_STATS if os.environ.get('DIAG') else 0), want_fix=False)
         print(f"mode {mode} chunk {chunk} item_block {ib}: {st['kernel_ms']:.2f} ms cand/ray {st['candidates']/st['rays_traced']:.3f} roots/ray {st['exact_roots']/st['rays_traced']:.3f} grid {st['grid_blocks']}", flush=True)
         r.close()

@@ -17,7 +17,7 @@ for name, seed, grid, w, h, spp in cfgs:
     r.upload_scene(flat)
     cam = rt.book1_camera(w, h)
     t0 = time.perf_counter()
-    sm, fix, st = r.render(cam, rt.make_params(w, h, spp), want_fix=False)
+    sm, fix, st = r.render(cam, rt.make_params(w, h, spp, flags=rt.RT_FLAG_DIAG_STATS), want_fix=False)
     wall = time.perf_counter() - t0
     mean = sm.astype(np.float64).mean() / spp
     n = len(flat)
