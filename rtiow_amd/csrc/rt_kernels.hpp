@@ -98,9 +98,13 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
     // holds the passing result (ds_or, nothing returned, nothing waited for), read by the owner
     __shared__ unsigned int s_bits[MATRIX ? kBlock / 64 : 1][MATRIX ? kSegTiles / 2 : 1][MATRIX ? 64 : 1];
     __shared__ unsigned int s_sum[MATRIX ? kBlock : 1];     // per ray: which of its bitmap words are non-zero
+    // the item's running sums (exact u64 fixed point) live in LDS, not in 6 VGPRs: they are touched
+    // once per finished sample, and registers are what the 4th wave per SIMD is paid with
+    __shared__ unsigned long long s_acc[3][kBlock];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    s_acc[0][tid] = 0ull; s_acc[1][tid] = 0ull; s_acc[2][tid] = 0ull;    // own slots only: no barrier needed
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
 
     // The filter table is read-only for the whole launch and indexed by a
@@ -119,7 +123,6 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
     uint32_t pix_local = 0, pix_global = 0;
     int s = 0, s_end = 0;
     uint32_t px_i = 0, px_j = 0;
-    unsigned long long acc0 = 0, acc1 = 0, acc2 = 0;
     D3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1, 1, 1);
     int depth = 0;
     uint32_t ev = 0;
@@ -510,15 +513,19 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
                 if (depth <= 0) done = true;                                    // main.rs:40-42: L = 0
             }
             if (done) {
-                acc0 += quantize(L.x); acc1 += quantize(L.y); acc2 += quantize(L.z);
+                const unsigned long long a0 = s_acc[0][tid] + quantize(L.x);
+                const unsigned long long a1 = s_acc[1][tid] + quantize(L.y);
+                const unsigned long long a2 = s_acc[2][tid] + quantize(L.z);
                 alive = false;
                 n_samples++;
                 s++;
                 if (s >= s_end) {
                     unsigned long long *px = P.fix + (size_t)pix_local * 3u;
-                    atomicAdd(px + 0, acc0); atomicAdd(px + 1, acc1); atomicAdd(px + 2, acc2);
-                    acc0 = acc1 = acc2 = 0ull;
+                    atomicAdd(px + 0, a0); atomicAdd(px + 1, a1); atomicAdd(px + 2, a2);
+                    s_acc[0][tid] = 0ull; s_acc[1][tid] = 0ull; s_acc[2][tid] = 0ull;
                     has_item = false;
+                } else {
+                    s_acc[0][tid] = a0; s_acc[1][tid] = a1; s_acc[2][tid] = a2;
                 }
             }
         }
