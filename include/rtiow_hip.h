@@ -18,8 +18,9 @@
  *     rt_last_error() gives the thread-local message of the last failure;
  *   - the caller owns every buffer it passes; the library owns the device
  *     memory tied to an rt_context;
- *   - a context is used from one host thread at a time; distinct contexts
- *     (one per GPU) may be used concurrently;
+ *   - a context is used from one host thread at a time and has ONE render in
+ *     flight at a time (the work counter and statistics words belong to the
+ *     context); distinct contexts (one per GPU) may be used concurrently;
  *   - there is NO CPU fallback: without a usable gfx950 device rt_create fails.
  *
  * Arithmetic.  Results are those of the reference's own f64 arithmetic: every

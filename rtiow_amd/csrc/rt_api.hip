@@ -118,6 +118,21 @@ int ensure(void **ptr, size_t *have, size_t need)
     return RT_OK;
 }
 
+// K' of the scan filter for one sphere (rt_device.hpp):
+// |c|^2 (1-kappa) - r^2 (1+2 kappa) in f64, rounded DOWN to f32 (a smaller K' keeps more);
+// spheres outside f32's comfortable range get -inf: always kept.
+float filter_kprime(const rt_sphere &s, double KU)
+{
+    const double kappa = KU / (1.0 - KU);
+    const double r2 = s.radius * s.radius;
+    const double c2 = s.center[0] * s.center[0] + s.center[1] * s.center[1] + s.center[2] * s.center[2];
+    if (!(r2 > 1e-30) || !(c2 + r2 < 1e30)) return -INFINITY;
+    const double exact = c2 * (1.0 - kappa) - r2 * (1.0 + 2.0 * kappa);
+    float kp = (float)(exact - std::fabs(exact) * 1e-12);
+    if ((double)kp > exact) kp = std::nextafterf(kp, -INFINITY);
+    return kp;
+}
+
 template <int MODE, bool DIAG>
 int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, int *grid_out)
 {
@@ -229,8 +244,6 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
     const size_t cnt = (size_t)(n > 0 ? n : 1);
     std::vector<float> filt(cnt * 4, 0.0f);
     std::vector<double> geo(cnt * 4, 0.0), mat(cnt * rt::kMatStride, 0.0);
-    const double KU = (double)rt::kFilterKU;
-    const double kappa = KU / (1.0 - KU);
     for (int i = 0; i < n; ++i) {
         const rt_sphere &s = spheres[i];
         // exact records: radius*radius (sphere.rs:22) and 1.0/radius (vec3.rs:371-375 applied
@@ -251,14 +264,8 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
             r0 = (1.0 - s.param) / (1.0 + s.param); m[8] = r0 * r0;
             m[2] = 1.0; m[3] = 1.0; m[4] = 1.0;                                  // attenuation (1,1,1), :103
         }
-        // filter record (rt_device.hpp): centre rounded to f32 and
-        // K' = |c|^2 (1-kappa) - r^2 (1+2 kappa), rounded DOWN (a smaller K' keeps more)
-        const double c2 = s.center[0] * s.center[0] + s.center[1] * s.center[1] + s.center[2] * s.center[2];
-        const double kp_exact = c2 * (1.0 - kappa) - r2 * (1.0 + 2.0 * kappa);
-        float kp = (float)(kp_exact - std::fabs(kp_exact) * 1e-12);
-        if ((double)kp > kp_exact) kp = std::nextafterf(kp, -INFINITY);
-        // spheres outside f32's comfortable range always go to the exact test
-        if (!(r2 > 1e-30) || !(c2 + r2 < 1e30)) kp = -INFINITY;
+        // filter record: centre rounded to f32 + K' for the f32 evaluation schemes
+        const float kp = filter_kprime(s, (double)rt::kFilterKU);
         filt[4 * i + 0] = (float)s.center[0]; filt[4 * i + 1] = (float)s.center[1];
         filt[4 * i + 2] = (float)s.center[2]; filt[4 * i + 3] = kp;
     }
@@ -310,22 +317,8 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
         const uint32_t y3 = bf16_rne(r2);
         bmat16[e] = make_uint4(y1 | (y2 << 16), y1 | (y3 << 16), y2 | (y1 << 16), y3 | (y2 << 16));
     }
-    {
-        const double KU3 = (double)rt::kFilterKU_bf16x3, kappa3 = KU3 / (1.0 - KU3);
-        for (int i = 0; i < n; ++i) {
-            const rt_sphere &sp = spheres[i];
-            const double r2 = sp.radius * sp.radius;
-            const double cf[3] = { (double)filt[4 * i], (double)filt[4 * i + 1], (double)filt[4 * i + 2] };
-            (void)cf;
-            const double c2 = sp.center[0] * sp.center[0] + sp.center[1] * sp.center[1] + sp.center[2] * sp.center[2];
-            const double kp_exact = c2 * (1.0 - kappa3) - r2 * (1.0 + 2.0 * kappa3);
-            float kpv = (float)(kp_exact - std::fabs(kp_exact) * 1e-12);
-            if ((double)kpv > kp_exact) kpv = std::nextafterf(kpv, -INFINITY);
-            if (!(r2 > 1e-30) || !(c2 + r2 < 1e30)) kpv = -INFINITY;
-            kpt16[i] = kpv;
-        }
-        for (int e = 0; e < ctx->n_always; ++e) kpt16[ctx->always_idx[e]] = NAN;
-    }
+    for (int i = 0; i < n; ++i) kpt16[i] = filter_kprime(spheres[i], (double)rt::kFilterKU_bf16x3);
+    for (int e = 0; e < ctx->n_always; ++e) kpt16[ctx->always_idx[e]] = NAN;
     RT_HIP(hipMalloc((void **)&ctx->d_bmat16, tcnt * 64 * sizeof(uint4)));
     RT_HIP(hipMalloc((void **)&ctx->d_kpt16, tcnt * 16 * sizeof(float)));
     RT_HIP(hipMemcpy(ctx->d_bmat16, bmat16.data(), tcnt * 64 * sizeof(uint4), hipMemcpyHostToDevice));
