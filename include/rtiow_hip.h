@@ -183,6 +183,13 @@ int rt_f64_div_sqrt_device(rt_context *ctx, const double *a, const double *b, in
  * columns, out_hb, out_q: [64][16].  bf16x3 != 0 selects the three-piece bf16 form. */
 int rt_filter_products_device(rt_context *ctx, const float *r1, const float *r2, const float *s,
                                int32_t bf16x3, float *out_hb, float *out_q);
+/* One tile of the single-contraction ("lifted") form of the same filter, the shipped scan mode:
+ * o, d: [64][3] f64 rays; spheres16: 16 spheres (one tile of columns, built exactly as
+ * rt_upload_scene builds them); out_D: [64][16] the sums whose sign the kernel tests;
+ * out_R: [64][11] the per-ray terms (the last entry: 1 if the ray is inside the analysed range);
+ * out_C: [16][11] the per-sphere terms. */
+int rt_filter_lifted_device(rt_context *ctx, const double *o, const double *d, const rt_sphere *spheres16,
+                            float *out_D, float *out_R, float *out_C);
 int rt_philox_device(rt_context *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 #ifdef __cplusplus

@@ -59,6 +59,7 @@ SYMBOLS = [
     ("rt_philox_device", C.c_int, [_VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("rt_f64_div_sqrt_device", C.c_int, [_VP, _VP, _VP, C.c_int32, _VP, _VP]),
     ("rt_filter_products_device", C.c_int, [_VP, _VP, _VP, _VP, C.c_int32, _VP, _VP]),
+    ("rt_filter_lifted_device", C.c_int, [_VP, _VP, _VP, C.POINTER(rt_sphere), _VP, _VP, _VP]),
 ]
 
 _lib = None

@@ -55,11 +55,12 @@ struct rt_context {
     float *d_bmat = nullptr;       // [tiles][64] MFMA B operand of the filter
     float *d_kpt = nullptr;        // [tiles][16] K' per sphere
     uint4 *d_bmat16 = nullptr;     // [tiles][64] bf16x3 B operand
+    uint4 *d_bmatL = nullptr;      // [tiles][2][64] MODE 4 (lifted form) B operands
     float *d_kpt16 = nullptr;      // [tiles][16] K' for the bf16x3 form
     int n_tiles = 0;
     int n_always = 0;
     int always_idx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int scan_mode = 3;             // filter: 1 VALU + scalar loads, 2 f32 MFMA, 3 bf16x3 MFMA (default)
+    int scan_mode = 4;             // filter: 1 VALU + scalar loads, 2 f32 MFMA, 3 bf16x3 MFMA, 4 lifted bf16x3 MFMA (default)
     int n_spheres = -1;
     unsigned int *d_queue = nullptr;
     unsigned long long *d_stats = nullptr;
@@ -133,6 +134,65 @@ float filter_kprime(const rt_sphere &s, double KU)
     return kp;
 }
 
+// ---- MODE 4 (lifted form, rt_device.hpp): the per-sphere column C_0..C_10 and its 64 K-slots ----
+// `s == nullptr` (padding) or `never` (a sphere on the always-exact list): a column no ray keeps.
+// Every C_k is computed in f64 from the exact centre/radius and rounded once; C_10 = -K' is
+// rounded UP (K' down), the conservative direction.
+void lifted_column(const rt_sphere *s, bool never, float C[rt::kLiftTerms])
+{
+    for (int k = 0; k < rt::kLiftTerms; ++k) C[k] = 0.0f;
+    C[0] = 1.0f;
+    if (!s || never) { C[10] = rt::kLiftNever; return; }
+    const float kp = filter_kprime(*s, (double)rt::kFilterKU_lifted);
+    if (!(kp > -INFINITY)) { C[10] = rt::kLiftAlways; return; }       // outside the analysed range
+    const double cx = s->center[0], cy = s->center[1], cz = s->center[2];
+    C[1] = (float)cx; C[2] = (float)cy; C[3] = (float)cz;
+    C[4] = (float)(cx * cx); C[5] = (float)(cy * cy); C[6] = (float)(cz * cz);
+    C[7] = (float)(cx * cy); C[8] = (float)(cx * cz); C[9] = (float)(cy * cz);
+    C[10] = -kp;
+}
+uint32_t host_bf16_rne(float x)
+{
+    uint32_t u; memcpy(&u, &x, 4);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+void host_split_bf16x3(float x, uint32_t p[3])
+{
+    auto back = [](uint32_t b) { uint32_t u = b << 16; float f; memcpy(&f, &u, 4); return f; };
+    p[0] = host_bf16_rne(x);
+    const float r1 = x - back(p[0]);
+    p[1] = host_bf16_rne(r1);
+    const float r2 = r1 - back(p[1]);
+    p[2] = host_bf16_rne(r2);
+}
+// B-side dwords of the slot layout documented at lifted_a_words()
+void lifted_b_words(const float C[rt::kLiftTerms], uint32_t w[32])
+{
+    for (int p = 0; p < 9; ++p) {
+        uint32_t y[3]; host_split_bf16x3(C[1 + p], y);
+        w[3 * p + 0] = y[0] | (y[1] << 16);
+        w[3 * p + 1] = y[0] | (y[2] << 16);
+        w[3 * p + 2] = y[1] | (y[0] << 16);
+    }
+    uint32_t k[3]; host_split_bf16x3(C[10], k);
+    w[27] = rt::kBf16One | (rt::kBf16One << 16);      // C_0 = 1 against the three pieces of R_0
+    w[28] = rt::kBf16One | (k[0] << 16);
+    w[29] = k[1] | (k[2] << 16);
+    w[30] = 0u; w[31] = 0u;
+}
+// one tile (16 columns) of the B table: [m][lane] uint4, lane l = column l&15, K-slots 32m + 8(l>>4)..+7
+void lifted_tile(const float C[16][rt::kLiftTerms], uint4 out[128])
+{
+    for (int c = 0; c < 16; ++c) {
+        uint32_t w[32]; lifted_b_words(C[c], w);
+        for (int m = 0; m < 2; ++m)
+            for (int quad = 0; quad < 4; ++quad) {
+                const uint32_t *q = &w[4 * (4 * m + quad)];
+                out[m * 64 + quad * 16 + c] = make_uint4(q[0], q[1], q[2], q[3]);
+            }
+    }
+}
+
 template <int MODE, bool DIAG>
 int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, int *grid_out)
 {
@@ -188,8 +248,8 @@ int rt_create(int32_t device_id, rt_context **out)
     ctx->chunk = env_int("RTIOW_CHUNK", 0);
     ctx->item_block = env_int("RTIOW_ITEM_BLOCK", rt::kItemBlock);
     if (ctx->item_block < 64) ctx->item_block = 64;
-    ctx->scan_mode = env_int("RTIOW_SCAN_MODE", 3);
-    if (ctx->scan_mode < 1 || ctx->scan_mode > 3) ctx->scan_mode = 3;
+    ctx->scan_mode = env_int("RTIOW_SCAN_MODE", 4);
+    if (ctx->scan_mode < 1 || ctx->scan_mode > 4) ctx->scan_mode = 4;
     hipError_t e1 = hipMalloc((void **)&ctx->d_queue, 64);
     hipError_t e2 = hipMalloc((void **)&ctx->d_stats, 256);
     hipError_t e3 = hipEventCreate(&ctx->ev0);
@@ -210,6 +270,7 @@ int rt_destroy(rt_context *ctx)
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     (void)hipFree(ctx->d_filt); (void)hipFree(ctx->d_geo); (void)hipFree(ctx->d_mat);
     (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt); (void)hipFree(ctx->d_bmat16); (void)hipFree(ctx->d_kpt16);
+    (void)hipFree(ctx->d_bmatL);
     (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->d_stage_fix); (void)hipFree(ctx->d_stage_sum); (void)hipFree(ctx->d_stage_rgba);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -238,8 +299,9 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
     RT_HIP(hipDeviceSynchronize());
     (void)hipFree(ctx->d_filt); (void)hipFree(ctx->d_geo); (void)hipFree(ctx->d_mat);
     (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt); (void)hipFree(ctx->d_bmat16); (void)hipFree(ctx->d_kpt16);
+    (void)hipFree(ctx->d_bmatL);
     ctx->d_filt = nullptr; ctx->d_geo = ctx->d_mat = nullptr; ctx->d_bmat = ctx->d_kpt = nullptr;
-    ctx->d_bmat16 = nullptr; ctx->d_kpt16 = nullptr;
+    ctx->d_bmat16 = nullptr; ctx->d_kpt16 = nullptr; ctx->d_bmatL = nullptr;
     ctx->n_spheres = -1;
     const size_t cnt = (size_t)(n > 0 ? n : 1);
     std::vector<float> filt(cnt * 4, 0.0f);
@@ -319,6 +381,21 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
     }
     for (int i = 0; i < n; ++i) kpt16[i] = filter_kprime(spheres[i], (double)rt::kFilterKU_bf16x3);
     for (int e = 0; e < ctx->n_always; ++e) kpt16[ctx->always_idx[e]] = NAN;
+    {   // MODE 4 table
+        std::vector<uint4> bmatL(tcnt * 128);
+        std::vector<char> never(n > 0 ? n : 1, 0);
+        for (int e = 0; e < ctx->n_always; ++e) never[ctx->always_idx[e]] = 1;
+        for (size_t t = 0; t < tcnt; ++t) {
+            float C[16][rt::kLiftTerms];
+            for (int c = 0; c < 16; ++c) {
+                const long i = 16 * (long)t + c;
+                lifted_column(i < n ? &spheres[i] : nullptr, i < n && never[i], C[c]);
+            }
+            lifted_tile(C, &bmatL[t * 128]);
+        }
+        RT_HIP(hipMalloc((void **)&ctx->d_bmatL, tcnt * 128 * sizeof(uint4)));
+        RT_HIP(hipMemcpy(ctx->d_bmatL, bmatL.data(), tcnt * 128 * sizeof(uint4), hipMemcpyHostToDevice));
+    }
     RT_HIP(hipMalloc((void **)&ctx->d_bmat16, tcnt * 64 * sizeof(uint4)));
     RT_HIP(hipMalloc((void **)&ctx->d_kpt16, tcnt * 16 * sizeof(float)));
     RT_HIP(hipMemcpy(ctx->d_bmat16, bmat16.data(), tcnt * 64 * sizeof(uint4), hipMemcpyHostToDevice));
@@ -391,7 +468,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.npix = (uint32_t)npix; kp.total_items = (uint32_t)(npix * nchunks);
     kp.filt = ctx->d_filt; kp.geo = ctx->d_geo; kp.mat = ctx->d_mat;
     kp.bmat = ctx->d_bmat; kp.kpt = ctx->d_kpt; kp.n_tiles = ctx->n_tiles;
-    kp.bmat16 = ctx->d_bmat16; kp.kpt16 = ctx->d_kpt16;
+    kp.bmat16 = ctx->d_bmat16; kp.kpt16 = ctx->d_kpt16; kp.bmatL = ctx->d_bmatL;
     kp.n_always = ctx->n_always;
     for (int e = 0; e < 8; ++e) kp.always_idx[e] = ctx->always_idx[e];
     kp.fix = (unsigned long long *)d_fix;
@@ -427,7 +504,9 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     case 4: rc = launch_render<2, false>(ctx, kp, stream, &grid); break;
     case 5: rc = launch_render<2, true>(ctx, kp, stream, &grid); break;
     case 6: rc = launch_render<3, false>(ctx, kp, stream, &grid); break;
-    default: rc = launch_render<3, true>(ctx, kp, stream, &grid); break;
+    case 7: rc = launch_render<3, true>(ctx, kp, stream, &grid); break;
+    case 8: rc = launch_render<4, false>(ctx, kp, stream, &grid); break;
+    default: rc = launch_render<4, true>(ctx, kp, stream, &grid); break;
     }
     if (rc) return rc;
     ctx->launched = true;
@@ -455,7 +534,7 @@ int rt_last_stats(rt_context *ctx, rt_stats *stats)
     return RT_OK;
 }
 
-#ifdef RT_PHASE_STAMPS
+#if defined(RT_PHASE_STAMPS) || defined(RT_BLOCK_COUNTS)
 extern "C" int rt_debug_phase_cycles(rt_context *ctx, unsigned long long out[8])
 {
     RT_HIP(hipSetDevice(ctx->device));
@@ -587,6 +666,35 @@ int rt_filter_products_device(rt_context *ctx, const float *r1, const float *r2,
     RT_HIP(hipGetLastError());
     RT_HIP(hipMemcpyAsync(out_hb, d_hb, 1024 * 4, hipMemcpyDeviceToHost, ctx->own_stream));
     RT_HIP(hipMemcpyAsync(out_q, d_q, 1024 * 4, hipMemcpyDeviceToHost, ctx->own_stream));
+    RT_HIP(hipStreamSynchronize(ctx->own_stream));
+    return RT_OK;
+}
+
+int rt_filter_lifted_device(rt_context *ctx, const double *o, const double *d, const rt_sphere *spheres16,
+                            float *out_D, float *out_R, float *out_C)
+{
+    if (!ctx || !o || !d || !spheres16 || !out_D || !out_R || !out_C) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    RT_HIP(hipSetDevice(ctx->device));
+    float C[16][rt::kLiftTerms];
+    for (int c = 0; c < 16; ++c) lifted_column(&spheres16[c], false, C[c]);
+    memcpy(out_C, C, sizeof(C));
+    uint4 tile[128];
+    lifted_tile(C, tile);
+    const size_t in_b = 64 * 3 * 8 * 2 + sizeof(tile), out_b = (64 * 16 + 64 * rt::kLiftTerms) * 4;
+    int rc = ensure(&ctx->d_stage_fix, &ctx->stage_fix_bytes, in_b + out_b);
+    if (rc) return rc;
+    char *base = (char *)ctx->d_stage_fix;
+    double *d_o = (double *)base, *d_d = d_o + 192;
+    uint4 *d_tile = (uint4 *)(base + 3072);
+    float *d_D = (float *)(base + 3072 + sizeof(tile)), *d_R = d_D + 1024;
+    RT_HIP(hipMemcpyAsync(d_o, o, 1536, hipMemcpyHostToDevice, ctx->own_stream));
+    RT_HIP(hipMemcpyAsync(d_d, d, 1536, hipMemcpyHostToDevice, ctx->own_stream));
+    RT_HIP(hipMemcpyAsync(d_tile, tile, sizeof(tile), hipMemcpyHostToDevice, ctx->own_stream));
+    hipLaunchKernelGGL(rt::lifted_products_kernel, dim3(1), dim3(64), 0, ctx->own_stream,
+                       (const double *)d_o, (const double *)d_d, (const uint4 *)d_tile, d_D, d_R);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemcpyAsync(out_D, d_D, 1024 * 4, hipMemcpyDeviceToHost, ctx->own_stream));
+    RT_HIP(hipMemcpyAsync(out_R, d_R, 64 * rt::kLiftTerms * 4, hipMemcpyDeviceToHost, ctx->own_stream));
     RT_HIP(hipStreamSynchronize(ctx->own_stream));
     return RT_OK;
 }

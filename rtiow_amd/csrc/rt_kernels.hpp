@@ -50,6 +50,7 @@ struct KParams {
     const float *kpt;          // [tiles][16] K' per sphere (NaN: never kept by the filter)
     const uint4 *bmat16;       // [tiles][64] bf16x3 B operand: 8 bf16 (y1,y2,y1,y3,y2,y1,y3,y2) of S[k][sphere]
     const float *kpt16;        // [tiles][16] K' for the bf16x3 form (larger KU)
+    const uint4 *bmatL;        // [tiles][2][64] MODE 4 B operands: the 64 K-slots of the lifted form (rt_device.hpp)
     int32_t n_tiles;
     int32_t n_always;          // spheres that skip the filter and are always tested exactly
     int32_t always_idx[8];
@@ -80,6 +81,9 @@ __device__ __forceinline__ D3 ld3(const double *p) { return mk(p[0], p[1], p[2])
 // MODE 3: the same two products on the bf16 matrix pipe (16x the f32 rate): every f32 operand
 //         is the exact sum of three bf16 pieces, and one v_mfma_f32_16x16x32_bf16 adds up the
 //         8 significant piece products of each of the 4 components (K = 32).
+// MODE 4: the filter as ONE contraction of 11 per-ray terms with 11 per-sphere terms (rt_device.hpp,
+//         "lifted" form) on the bf16 matrix pipe, two chained K = 32 MFMAs per 16 rays x 16 spheres:
+//         the VALU no longer squares and subtracts, it only looks at the sign of the result.
 constexpr int kRowPad = 80;         // floats per row of the ray-operand transpose buffer
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -89,14 +93,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int MODE, bool DIAG>
 // second launch bound = waves per SIMD the register allocator must leave room for: the bounce loop
 // is latency-bound, and the 4th wave is worth more than the few cold values it spills
-__global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void render_kernel(const KParams P)
+__global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(const KParams P)
 {
     __shared__ uint16_t cand[MODE == 1 ? kCandCap : 1][kBlock];     // MODE 1: per-lane candidate lists
-    constexpr bool MATRIX = (MODE == 2 || MODE == 3);
-    __shared__ float s_rayop[MATRIX ? kBlock / 64 : 1][MATRIX ? 8 : 1][MATRIX ? kRowPad : 1];
+    constexpr bool MATRIX = (MODE >= 2);
+    constexpr bool LIFTED = (MODE == 4);
+    __shared__ float s_rayop[(MATRIX && !LIFTED) ? kBlock / 64 : 1][(MATRIX && !LIFTED) ? 8 : 1][(MATRIX && !LIFTED) ? kRowPad : 1];
     // per ray, one bit per sphere of the current segment (kSegTiles tiles): set by whichever lane
     // holds the passing result (ds_or, nothing returned, nothing waited for), read by the owner
-    __shared__ unsigned int s_bits[MATRIX ? kBlock / 64 : 1][MATRIX ? kSegTiles / 2 : 1][MATRIX ? 64 : 1];
+    // (MODE 4: the same LDS first carries the per-ray operand dwords to the MFMA layout)
+    static_assert((kSegTiles / 2) * 64 * sizeof(unsigned int) >= 32 * kStageStride * sizeof(uint4), "operand staging fits the bitmap");
+    __shared__ __attribute__((aligned(16))) unsigned int s_bits[MATRIX ? kBlock / 64 : 1][MATRIX ? kSegTiles / 2 : 1][MATRIX ? 64 : 1];
     __shared__ unsigned int s_sum[MATRIX ? kBlock : 1];     // per ray: which of its bitmap words are non-zero
     // the item's running sums (exact u64 fixed point) live in LDS, not in 6 VGPRs: they are touched
     // once per finished sample, and registers are what the 4th wave per SIMD is paid with
@@ -136,10 +143,19 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #define RT_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); \
                          __builtin_amdgcn_s_waitcnt(0); ph[k] += tn_ - tprev; tprev = tn_; } while (0)
+#define RT_COUNT(k) do { } while (0)
+#elif defined(RT_BLOCK_COUNTS)
+    // Diagnostic build only: wave-level execution counts of the main blocks, into stats[8..15].
+    __shared__ unsigned int s_cnt[kBlock / 64][8];
+    if ((tid & 63) < 8) s_cnt[tid >> 6][tid & 7] = 0u;
+#define RT_STAMP(k) do { } while (0)
+#define RT_COUNT(k) do { if ((int)(tid & 63) == (int)__builtin_ctzll(__ballot(true))) s_cnt[tid >> 6][k] += 1u; } while (0)
 #else
 #define RT_STAMP(k) do { } while (0)
+#define RT_COUNT(k) do { } while (0)
 #endif
     for (;;) {
+        RT_COUNT(0);
         // ---- (a) idle lanes take work items ------------------------------------
         // A wave reserves kItemBlock consecutive items with ONE returning atomic on the
         // device-wide counter and deals them to its lanes (ballot -> popcount -> prefix rank)
@@ -185,12 +201,14 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
         RT_STAMP(0);
         // ---- (b) start the next sample: main.rs:131-134 + camera.rs:47-54 ----
         if (has_item && !alive) {
+            RT_COUNT(1);
             U4 w = philox4x32_10(pix_global, (uint32_t)s, 0u, 0u, P.k0, P.k1);
             ev = 1u;
             const double u = ((double)px_i + u01(w.x)) / wm1;       // main.rs:131
             const double v = ((double)px_j + u01(w.y)) / hm1;       // main.rs:132
             double lx = u11(w.z), ly = u11(w.w);
             while (!(length_squared(mk(lx, ly, 0.0)) < 1.0)) {      // vec3.rs:59-68
+                RT_COUNT(2);
                 w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
                 ev++;
                 lx = u11(w.x); ly = u11(w.y);
@@ -256,6 +274,155 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
         if (MATRIX) {
             // ---- the filter on the matrix pipe: the whole wave takes part ------------
             const int wave = tid >> 6;
+            const int col = lane & 15, quad = lane >> 4;
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            unsigned int *bits_w = &s_bits[wave][0][0];             // [word][ray]
+            unsigned int *sum_w = &s_sum[wave * 64];
+            // Results of half a tile: Dv[g][i] belongs to ray 16(2h+g) + 4 quad + i and sphere
+            // 16 t + col; it is kept iff Dv >= kp.  Hits are rare, so the eight values are first
+            // folded into one maximum and one wave-level branch.
+            auto check_half = [&](int h, const float (&Dv)[2][4], float kp, int trel) {
+                const float m01 = __builtin_fmaxf(__builtin_fmaxf(Dv[0][0], Dv[0][1]), Dv[0][2]);
+                const float m02 = __builtin_fmaxf(__builtin_fmaxf(m01, Dv[0][3]), Dv[1][0]);
+                const float m03 = __builtin_fmaxf(__builtin_fmaxf(m02, Dv[1][1]), Dv[1][2]);
+                const float mall = __builtin_fmaxf(m03, Dv[1][3]);
+                if (__builtin_expect(__ballot(mall >= kp) != 0ull, 0)) {
+                    RT_COUNT(3);
+                    const unsigned bit = 1u << ((trel & 1) * 16 + col);
+                    const unsigned wbit = 1u << (trel >> 1);
+                    unsigned int *row = bits_w + (trel >> 1) * 64;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const float mG = __builtin_fmaxf(__builtin_fmaxf(Dv[g][0], Dv[g][1]), __builtin_fmaxf(Dv[g][2], Dv[g][3]));
+                        if (__ballot(mG >= kp) != 0ull) {
+                            RT_COUNT(4);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)             // (a lane without a ray can land here
+                                if (Dv[g][i] >= kp) {               //  only via an always-kept column; harmless)
+                                    const int ray = 16 * (2 * h + g) + 4 * quad + i;
+                                    atomicOr(&row[ray], bit);
+                                    atomicOr(&sum_w[ray], wbit);
+                                }
+                        }
+                    }
+                }
+            };
+            // MODE 4: kept iff Dv >= 0.  Sign tests on the bit patterns (an exact zero cannot occur
+            // for a sphere the reference can hit: the slack kappa S is strictly positive), so the
+            // maxima are integer v_max3 with no NaN canonicalisation in front.
+            auto check_sign_half = [&](int h, const float (&Dv)[2][4], int trel) {
+                int iv[2][4];
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) iv[g][i] = __float_as_int(Dv[g][i]);
+                const int m0 = max(max(iv[0][0], iv[0][1]), iv[0][2]);
+                const int m1 = max(max(m0, iv[0][3]), iv[1][0]);
+                const int m2 = max(max(m1, iv[1][1]), iv[1][2]);
+                const int mall = max(m2, iv[1][3]);
+                if (__builtin_expect(__ballot(mall >= 0) != 0ull, 0)) {
+                    RT_COUNT(3);
+                    int colv = col;
+                    asm volatile("" : "+v"(colv));                  // keep the address arithmetic on this side of the branch
+                    const unsigned bit = 1u << ((trel & 1) * 16 + colv);
+                    const unsigned wbit = 1u << (trel >> 1);
+                    unsigned int *row = bits_w + (trel >> 1) * 64;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int mG = max(max(iv[g][0], iv[g][1]), max(iv[g][2], iv[g][3]));
+                        if (__ballot(mG >= 0) != 0ull) {
+                            RT_COUNT(4);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (iv[g][i] >= 0) {
+                                    const int ray = 16 * (2 * h + g) + 4 * quad + i;
+                                    atomicOr(&row[ray], bit);
+                                    atomicOr(&sum_w[ray], wbit);
+                                }
+                        }
+                    }
+                }
+            };
+            // The owner walks its candidates straight off the bitmap, in ascending sphere order:
+            // `summary` says which words are non-zero, `word` holds the bits left in the current
+            // one.  Trip count = the longest candidate list in the wave.
+            auto walk_bitmap = [&](int seg0) {
+                unsigned summary = s_sum[tid], word = 0u;
+                int wbase = 0;
+                while (__any((summary | word) != 0u)) {
+                    RT_COUNT(5);
+                    if ((summary | word) != 0u) {
+                        if (word == 0u) {
+                            const int w = __builtin_ctz(summary);
+                            summary &= summary - 1u;
+                            word = bits_w[w * 64 + lane];
+                            wbase = 16 * seg0 + 32 * w;
+                        }
+                        const int bpos = __builtin_ctz(word);
+                        word &= word - 1u;
+                        if (DIAG) n_cand++;
+                        exact_test(wbase + bpos);
+                    }
+                }
+            };
+            const int nt = P.n_tiles;                   // even; the tables hold nt + 2 tiles
+
+            if constexpr (LIFTED) {
+                const LiftedRay L = alive ? make_lifted(o, d) : no_lifted_ray();
+                bf16x8 A[4][2];
+                {
+                    uint32_t w[32];
+                    lifted_a_words(L, w);
+                    lifted_stage_operands(reinterpret_cast<uint4 *>(bits_w), lane, w, A);
+                }
+                if (alive) {
+                    for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e]); }
+                    // outside the analysed range: everything is tested exactly
+                    if (!L.sane) for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i); }
+                }
+                // B operands: 2 KB per tile, lane l reads 16 bytes at 16 l of each half; a raw buffer
+                // load takes the lane part from a VGPR that never changes and the tile part from
+                // an SGPR: no vector address arithmetic in the loop
+                const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<uint4 *>(P.bmatL), 0, (nt + 2) * 2048, 0x00020000);
+                const int voff = lane * 16;
+                auto load_b = [&](int tile, int m) -> bf16x8 {
+                    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, voff, (2 * tile + m) * 1024, 0));
+                };
+                RT_STAMP(5);
+                for (int seg0 = 0; seg0 < nt; seg0 += kSegTiles) {
+                    const int seg_n = min(kSegTiles, nt - seg0);
+                    const int nwords = seg_n >> 1;
+                    for (int w = 0; w < nwords; ++w) bits_w[w * 64 + lane] = 0u;
+                    s_sum[tid] = 0u;
+                    __builtin_amdgcn_wave_barrier();
+                    // one tile: 2 ray-group pairs x (2 chained MFMAs each), sign look after each pair;
+                    // two ray groups interleaved so a chained MFMA never waits on its own input
+                    auto do_tile = [&](int tr, const bf16x8 &b0, const bf16x8 &b1) {
+                        RT_COUNT(7);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2 * h][0], b0, zero, 0, 0, 0);
+                            f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2 * h + 1][0], b0, zero, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2 * h][1], b1, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2 * h + 1][1], b1, acc1, 0, 0, 0);
+                            const float Dv[2][4] = {{acc0[0], acc0[1], acc0[2], acc0[3]}, {acc1[0], acc1[1], acc1[2], acc1[3]}};
+                            check_sign_half(h, Dv, tr);
+                        }
+                    };
+                    // B operands ping-pong between two register sets, each fetched a tile ahead
+                    bf16x8 p0 = load_b(seg0, 0), p1 = load_b(seg0, 1), q0, q1;
+                    for (int tr = 0; tr < seg_n; tr += 2) {             // seg_n is even
+                        q0 = load_b(seg0 + tr + 1, 0); q1 = load_b(seg0 + tr + 1, 1);
+                        do_tile(tr, p0, p1);
+                        p0 = load_b(seg0 + tr + 2, 0); p1 = load_b(seg0 + tr + 2, 1);
+                        do_tile(tr + 1, q0, q1);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    RT_STAMP(6);
+                    if (alive) walk_bitmap(seg0);
+                }
+            } else {
             RayFilter f;
             if (alive) {
                 f = make_filter<MODE == 3>(o, d);
@@ -268,7 +435,6 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
             rop[4 * kRowPad + lane] = f.px;  rop[5 * kRowPad + lane] = f.py;
             rop[6 * kRowPad + lane] = f.pz;  rop[7 * kRowPad + lane] = f.o2;
             __builtin_amdgcn_wave_barrier();            // LDS ops of one wave execute in order
-            const int col = lane & 15, quad = lane >> 4;
             // A operands: lane l holds R[ray 16G + (l&15)][k = l>>4]
             typedef typename std::conditional<MODE == 3, bf16x8, float>::type aop_t;
             typedef typename std::conditional<MODE == 3, uint4, float>::type bop_t;
@@ -280,7 +446,6 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
                 if constexpr (MODE == 3) { A_hb[G] = a_operand_bf16x3(vh); A_q[G] = a_operand_bf16x3(vq); }
                 else { A_hb[G] = vh; A_q[G] = vq; }
             }
-            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
             const bop_t *btab;
             const float *ktab;
             if constexpr (MODE == 3) { btab = P.bmat16; ktab = P.kpt16; } else { btab = P.bmat; ktab = P.kpt; }
@@ -298,45 +463,25 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
                     }
                 }
             };
-            // results of half a tile: D'' for rays 16G + 4 quad + i (G = 2h+g) against sphere 16t + col
+            // D'' = hb^2 - q for the 8 results per lane of half a tile
             auto look_half = [&](int h, const f32x4 (&hb)[2], const f32x4 (&q)[2], float kp, int trel) {
-                float Dv[2][4], mG[2];
+                float Dv[2][4];
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < 2; ++g)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) Dv[g][i] = __builtin_fmaf(hb[g][i], hb[g][i], -q[g][i]);
-                    mG[g] = __builtin_fmaxf(__builtin_fmaxf(Dv[g][0], Dv[g][1]), __builtin_fmaxf(Dv[g][2], Dv[g][3]));
-                }
-                if (__builtin_expect(__ballot(__builtin_fmaxf(mG[0], mG[1]) >= kp) != 0ull, 0)) {
-                    const unsigned bit = 1u << ((trel & 1) * 16 + col);
-                    const unsigned wbit = 1u << (trel >> 1);
-                    unsigned int *row = &s_bits[wave][trel >> 1][0];
-                    unsigned int *sum = &s_sum[wave * 64];
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        if (__ballot(mG[g] >= kp) != 0ull) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)             // (a ray without a path can land here
-                                if (Dv[g][i] >= kp) {               //  only via K' = -inf; harmless)
-                                    const int ray = 16 * (2 * h + g) + 4 * quad + i;
-                                    atomicOr(&row[ray], bit);
-                                    atomicOr(&sum[ray], wbit);
-                                }
-                        }
-                    }
-                }
+                check_half(h, Dv, kp, trel);
             };
             if (alive) {
                 for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e]); }
                 // outside the analysed range: everything is tested exactly
                 if (!f.sane) for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i); }
             }
-            const int nt = P.n_tiles;                   // even; the tables hold nt + 2 tiles
             RT_STAMP(5);
             for (int seg0 = 0; seg0 < nt; seg0 += kSegTiles) {
                 const int seg_n = min(kSegTiles, nt - seg0);
                 const int nwords = seg_n >> 1;
-                for (int w = 0; w < nwords; ++w) s_bits[wave][w][lane] = 0u;
+                for (int w = 0; w < nwords; ++w) bits_w[w * 64 + lane] = 0u;
                 s_sum[tid] = 0u;
                 __builtin_amdgcn_wave_barrier();
                 // Half a tile at a time: 4 MFMAs (2 ray groups x {HB, Q}), then the VALU looks at the
@@ -347,6 +492,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
                 bop_t b_cur = btab[seg0 * 64 + lane];
                 float k_cur = ktab[seg0 * 16 + col];
                 for (int tr = 0; tr < seg_n; ++tr) {
+                    RT_COUNT(7);
                     const bop_t b_next = btab[(seg0 + tr + 1) * 64 + lane];
                     const float k_next = ktab[(seg0 + tr + 1) * 16 + col];
                     mfma_half(0, b_cur, hbA, qA);
@@ -357,27 +503,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
                 }
                 __builtin_amdgcn_wave_barrier();
                 RT_STAMP(6);
-                if (alive) {
-                    // The owner walks its candidates straight off the bitmap, in ascending sphere
-                    // order: `summary` says which words are non-zero, `word` holds the bits left
-                    // in the current one.  Trip count = the longest candidate list in the wave.
-                    unsigned summary = s_sum[tid], word = 0u;
-                    int wbase = 0;
-                    while (__any((summary | word) != 0u)) {
-                        if ((summary | word) != 0u) {
-                            if (word == 0u) {
-                                const int w = __builtin_ctz(summary);
-                                summary &= summary - 1u;
-                                word = s_bits[wave][w][lane];
-                                wbase = 16 * seg0 + 32 * w;
-                            }
-                            const int bpos = __builtin_ctz(word);
-                            word &= word - 1u;
-                            if (DIAG) n_cand++;
-                            exact_test(wbase + bpos);
-                        }
-                    }
-                }
+                if (alive) walk_bitmap(seg0);
+            }
             }
         }
         RT_STAMP(2);
@@ -455,6 +582,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
                 nrm = front ? outward : (mk(0.0, 0.0, 0.0) - outward);
                 if (kind != RT_KIND_DIALECTRIC) {
                     do {                                                         // vec3.rs:37-45
+                        RT_COUNT(6);
                         const U4 w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
                         ev++;
                         sp = mk(u11(w.x), u11(w.y), u11(w.z));
@@ -534,8 +662,10 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 3) ? 4 : 5) void rend
 
         // (end of the bounce loop body is stamped at the top of the next iteration as phase 4)
     // wave totals -> device counters
-#ifdef RT_PHASE_STAMPS
+#if defined(RT_PHASE_STAMPS)
     if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(P.stats + 8 + k, ph[k]);
+#elif defined(RT_BLOCK_COUNTS)
+    if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(P.stats + 8 + k, (unsigned long long)s_cnt[tid >> 6][k]);
 #endif
     {
         unsigned long long ns = n_samples;
@@ -632,6 +762,31 @@ __global__ __launch_bounds__(64) void filter_products_kernel(const float *r1, co
             hb_out[(16 * G + 4 * quad + i) * 16 + col] = hb[i];
             q_out[(16 * G + 4 * quad + i) * 16 + col] = q[i];
         }
+    }
+}
+
+// One tile of the MODE 4 filter exactly as the render kernel evaluates it: 64 rays (o, d in f64,
+// [64][3]) against the 16 columns of `tile` ([2][64] B operands built by the host exactly as
+// rt_upload_scene builds them).  D_out[ray][column], R_out[ray][0..10] = the per-ray terms.
+__global__ __launch_bounds__(64) void lifted_products_kernel(const double *o, const double *d, const uint4 *tile,
+                                                           float *D_out, float *R_out)
+{
+    __shared__ uint4 stage[32 * kStageStride];
+    const int lane = threadIdx.x, col = lane & 15, quad = lane >> 4;
+    const LiftedRay L = make_lifted(mk(o[3 * lane], o[3 * lane + 1], o[3 * lane + 2]),
+                                    mk(d[3 * lane], d[3 * lane + 1], d[3 * lane + 2]));
+    for (int k = 0; k < kLiftTerms - 1; ++k) R_out[lane * kLiftTerms + k] = L.r[k];
+    R_out[lane * kLiftTerms + kLiftTerms - 1] = L.sane ? 1.0f : 0.0f;
+    bf16x8 A[4][2];
+    uint32_t w[32];
+    lifted_a_words(L, w);
+    lifted_stage_operands(stage, lane, w, A);
+    const bf16x8 b0 = __builtin_bit_cast(bf16x8, tile[lane]), b1 = __builtin_bit_cast(bf16x8, tile[64 + lane]);
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int G = 0; G < 4; ++G) {
+        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[G][0], b0, zero, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[G][1], b1, acc, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) D_out[(16 * G + 4 * quad + i) * 16 + col] = acc[i];
     }
 }
 

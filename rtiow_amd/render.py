@@ -147,6 +147,24 @@ class Renderer:
                    "rt_filter_products_device")
         return hb, q
 
+    def filter_lifted(self, o, d, spheres16):
+        """One tile of the single-contraction filter (the shipped scan mode), as the kernel evaluates it.
+
+        o, d: (64, 3) f64 rays; spheres16: structured array (SPHERE_DTYPE) of 16 spheres.
+        Returns D (64, 16) f32, R (64, 11) f32 per-ray terms, C (16, 11) f32 per-sphere terms."""
+        o = np.ascontiguousarray(o, dtype=np.float64).reshape(64, 3)
+        d = np.ascontiguousarray(d, dtype=np.float64).reshape(64, 3)
+        sp = np.ascontiguousarray(spheres16)
+        assert sp.shape == (16,) and sp.dtype.itemsize == C.sizeof(_ffi.rt_sphere)
+        D = np.zeros((64, 16), dtype=np.float32)
+        R = np.zeros((64, 11), dtype=np.float32)
+        Cc = np.zeros((16, 11), dtype=np.float32)
+        _ffi.check(self._lib.rt_filter_lifted_device(self._h, o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
+                                                     sp.ctypes.data_as(C.POINTER(_ffi.rt_sphere)),
+                                                     D.ctypes.data_as(C.c_void_p), R.ctypes.data_as(C.c_void_p),
+                                                     Cc.ctypes.data_as(C.c_void_p)), "rt_filter_lifted_device")
+        return D, R, Cc
+
     def philox(self, ctr, key):
         c = (C.c_uint32 * 4)(*ctr)
         k = (C.c_uint32 * 2)(*key)

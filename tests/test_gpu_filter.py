@@ -71,3 +71,86 @@ def test_bf16x3_split_is_exact(renderer):
     s[0, 0] = s[1, 1] = s[2, 2] = s[3, 3] = 1.0
     hb, q = renderer.filter_products(x, x, s, bf16x3=True)
     assert np.array_equal(hb[:, :4], x) and np.array_equal(q[:, :4], x)
+
+
+# ---- the shipped scan mode: the filter as ONE contraction of 11 terms (rt_device.hpp) ----------
+
+def _spheres16(c, r):
+    sp = np.zeros(16, dtype=rt.SPHERE_DTYPE)
+    sp["center"] = c
+    sp["radius"] = r
+    sp["albedo"] = 0.5
+    return sp
+
+
+def _lifted_exact(o, d, c, r, KU):
+    """The real-number value the contraction approximates, and the reference's discriminant / a."""
+    a = (d ** 2).sum(1)
+    g = d / np.sqrt(a * (1.0 - KU))[:, None]
+    kappa = KU / (1.0 - KU)
+    oc = o[:, None, :] - c[None, :, :]
+    hb = (oc * g[:, None, :]).sum(2)
+    lhs = hb ** 2 - (oc ** 2).sum(2) + (r ** 2)[None, :] \
+        + kappa * ((o ** 2).sum(1)[:, None] + (c ** 2).sum(1)[None, :] + 2.0 * (r ** 2)[None, :])
+    hbt = (oc * d[:, None, :]).sum(2)
+    disc = hbt ** 2 - a[:, None] * ((oc ** 2).sum(2) - (r ** 2)[None, :])
+    return lhs, disc
+
+
+def grazing_case(rng):
+    """Rays aimed at the rim of the spheres: disc / a within a few 1e-7 of zero, both signs."""
+    o, _, c, r = random_case(rng)
+    d = np.empty((64, 3))
+    for k in range(64):
+        j = 2 + k % 14
+        to_c = c[j] - o[k]
+        dist = np.linalg.norm(to_c)
+        axis = np.cross(to_c, rng.standard_normal(3)); axis /= np.linalg.norm(axis)
+        off = r[j] * (1.0 + rng.uniform(-3e-6, 3e-6))          # miss distance ~ r
+        ang = np.arcsin(min(1.0, off / dist))
+        w = to_c / dist
+        d[k] = (np.cos(ang) * w + np.sin(ang) * axis) * 10.0 ** rng.uniform(-2, 2)
+    return o, d, c, r
+
+
+def test_lifted_filter_within_the_proved_budget(renderer):
+    KU = 1024 * U
+    rng = np.random.default_rng(5)
+    worst_eval = 0.0
+    kept = total = hits = 0
+    for it in range(60):
+        o, d, c, r = grazing_case(rng) if it % 3 == 2 else random_case(rng)
+        D, R, C = renderer.filter_lifted(o, d, _spheres16(c, r))
+        assert np.all(R[:, 10] == 1.0)                         # every ray inside the analysed range
+        S = (o ** 2).sum(1)[:, None] + (c ** 2).sum(1)[None, :] + (r ** 2)[None, :]
+        # (1) the matrix pipe against exact arithmetic on the SAME f32 terms: dropped piece
+        #     products (2.01 u) + accumulation, budgeted 391 u S
+        Rx = R.astype(np.float64).copy(); Rx[:, 10] = 1.0
+        exact_terms = Rx @ C.astype(np.float64).T
+        worst_eval = max(worst_eval, float(np.max(np.abs(D - exact_terms) / (U * S))))
+        # (2) the whole chain (operand roundings included) against the real-number identity:
+        #     the kernel's value may fall short of it by less than the slack kappa S
+        lhs, disc = _lifted_exact(o, d, c, r, KU)
+        assert np.all(D.astype(np.float64) >= lhs - 460.0 * U * S), float(np.max((lhs - D) / (U * S)))
+        # (3) the conclusion itself: the reference can hit  =>  kept
+        assert not np.any((disc >= 0.0) & (D < 0.0))
+        kept += int((D >= 0.0).sum()); total += D.size; hits += int((disc >= 0.0).sum())
+    assert worst_eval < 391.0, worst_eval
+    print(f"lifted: worst |D - exact sum of terms| = {worst_eval:.2f} u S (budget 391); kept {kept} of {total}, "
+          f"reference can hit {hits}")
+
+
+def test_lifted_columns_outside_the_analysed_range_are_always_kept(renderer):
+    rng = np.random.default_rng(9)
+    o, d, c, r = random_case(rng)
+    c[3] = (1e16, 0.0, 0.0)              # |c|^2 + r^2 >= 1e30
+    r[4] = 1e-16                         # r^2 <= 1e-30
+    sp = _spheres16(c, r)
+    D, R, C = renderer.filter_lifted(o, d, sp)
+    assert np.all(D[:, 3] >= 0.0) and np.all(D[:, 4] >= 0.0)
+    # and rays outside it are flagged for the exhaustive exact scan
+    o2, d2 = o.copy(), d.copy()
+    d2[0] = (1e-11, 0.0, 0.0); d2[1] = (1e11, 0.0, 0.0); o2[2] = (1e16, 0.0, 0.0)
+    D, R, C = renderer.filter_lifted(o2, d2, sp)
+    assert list(R[:3, 10]) == [0.0, 0.0, 0.0] and np.all(R[3:, 10] == 1.0)
+    assert np.all(np.isfinite(D))

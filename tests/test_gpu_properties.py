@@ -129,11 +129,12 @@ def test_gpu_reproduces_the_reference_png_sky_rows(renderer, book1_flat):
 
 
 def test_all_scan_filters_give_the_same_bits(book1_flat, cfg2):
-    """The three filter implementations (VALU + scalar loads, f32 MFMA, bf16x3 MFMA) are three
-    ways of discarding spheres the reference cannot hit: the frame must not depend on which runs."""
+    """The four filter implementations (VALU + scalar loads, f32 MFMA, bf16x3 MFMA, single-contraction
+    bf16x3 MFMA) are four ways of discarding spheres the reference cannot hit: the frame must not
+    depend on which runs."""
     w, h, spp, fix, st = cfg2
     cands, roots = {}, set()
-    for mode in ("1", "2", "3"):
+    for mode in ("1", "2", "3", "4"):
         os.environ["RTIOW_SCAN_MODE"] = mode
         try:
             r = rt.Renderer(0)
@@ -148,6 +149,7 @@ def test_all_scan_filters_give_the_same_bits(book1_flat, cfg2):
         cands[mode] = st2["candidates"]
     assert len(roots) == 1                                  # the exact path sees the same real hits
     assert cands["1"] <= cands["2"] * 1.2 and cands["2"] <= cands["3"] * 1.01   # looser KU keeps more
+    assert cands["4"] <= cands["3"] * 1.05                  # same KU, same slack: about as selective
 
 
 def test_tenk_scene_full_size_properties(renderer):

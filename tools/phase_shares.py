@@ -4,10 +4,10 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa
 from rtiow_amd import _ffi
-_ffi.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtiow_hip_stamps.so")
+_ffi.LIB_PATH = os.environ.get("RTIOW_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtiow_hip_stamps.so")
 import rtiow_amd as rt
 names = ["(a) fetch item", "(b) camera ray", "(d) exact tests (list)", "-", "(e) shade+accumulate", "(d) operands + always-exact", "(d) matrix tile loop", "(d) bitmap -> list"]
-for mode in (3,):
+for mode in [int(x) for x in os.environ.get("MODES", "4").split(",")]:
     os.environ["RTIOW_SCAN_MODE"] = str(mode)
     r = rt.Renderer(0)
     r.upload_scene(rt.random_scene(1).flatten())
