@@ -190,6 +190,13 @@ int rt_filter_products_device(rt_context *ctx, const float *r1, const float *r2,
  * out_C: [16][11] the per-sphere terms. */
 int rt_filter_lifted_device(rt_context *ctx, const double *o, const double *d, const rt_sphere *spheres16,
                             float *out_D, float *out_R, float *out_C);
+/* One tile of the tube filter, the shipped scan mode: o, d: [64][3] f64 rays; spheres32: 32 spheres
+ * (one tile of columns, built exactly as rt_upload_scene builds them, radius floor included);
+ * out_h: [64][32][2] the two per-direction values whose magnitudes the kernel compares with
+ * out_bound[32]; out_rows: [64][9] = (lambda u_1, lambda u_2, t_1, t_2, 1 if the ray is inside the
+ * analysed range); out_rho: the radius floor chosen for these 32 spheres. */
+int rt_filter_tube_device(rt_context *ctx, const double *o, const double *d, const rt_sphere *spheres32,
+                          float *out_h, float *out_rows, float *out_bound, float *out_rho);
 int rt_philox_device(rt_context *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 #ifdef __cplusplus

@@ -56,11 +56,14 @@ struct rt_context {
     float *d_kpt = nullptr;        // [tiles][16] K' per sphere
     uint4 *d_bmat16 = nullptr;     // [tiles][64] bf16x3 B operand
     uint4 *d_bmatL = nullptr;      // [tiles][2][64] MODE 4 (lifted form) B operands
+    uint4 *d_btube = nullptr;      // [tiles/2 + 1][64] MODE 5 (tube filter) B operands
+    float *d_rtube = nullptr;      // [tiles/2 + 1][32] MODE 5 per-sphere bounds
+    float tube_rho = 1.0f;         // MODE 5 radius floor
     float *d_kpt16 = nullptr;      // [tiles][16] K' for the bf16x3 form
     int n_tiles = 0;
     int n_always = 0;
     int always_idx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int scan_mode = 4;             // filter: 1 VALU + scalar loads, 2 f32 MFMA, 3 bf16x3 MFMA, 4 lifted bf16x3 MFMA (default)
+    int scan_mode = 5;             // filter: 1 VALU + scalar loads, 2 f32 MFMA, 3 bf16x3 MFMA, 4 lifted bf16x3 MFMA, 5 tube bf16x2 MFMA (default)
     int n_spheres = -1;
     unsigned int *d_queue = nullptr;
     unsigned long long *d_stats = nullptr;
@@ -193,6 +196,59 @@ void lifted_tile(const float C[16][rt::kLiftTerms], uint4 out[128])
     }
 }
 
+// ---- MODE 5 (tube filter, rt_device.hpp): per-sphere columns and bounds ----
+// Radius floor rho: the rows of a ray are scaled by rho / (rho + e_ray), which keeps the test sound for
+// every sphere whose bound is >= rho; smaller spheres are tested with the bound rho.  The lower quartile
+// of the radii leaves three quarters of the scene untouched and keeps the scaling close to 1.
+float tube_radius_floor(const rt_sphere *spheres, int n, const char *skip)
+{
+    std::vector<double> r;
+    for (int i = 0; i < n; ++i)
+        if (!(skip && skip[i]) && std::fabs(spheres[i].radius) > 1e-15 && std::fabs(spheres[i].radius) < 1e15)
+            r.push_back(std::fabs(spheres[i].radius));
+    if (r.empty()) return 1.0f;
+    std::nth_element(r.begin(), r.begin() + r.size() / 4, r.end());
+    return (float)r[r.size() / 4];
+}
+// bound of one sphere: max(R, rho), R = r (1+64u) + 640u |c| rounded up; +inf outside the analysed range
+float tube_bound(const rt_sphere &s, float rho)
+{
+    const double r = std::fabs(s.radius);
+    const double c2 = s.center[0] * s.center[0] + s.center[1] * s.center[1] + s.center[2] * s.center[2];
+    if (!(r * r > 1e-30) || !(c2 + r * r < 1e30)) return INFINITY;
+    const double R = r * (1.0 + (double)rt::kTubeBasisErr) + (double)rt::kTubeCenterErr * std::sqrt(c2);
+    float f = (float)(R * (1.0 + 1e-12));
+    if ((double)f < R) f = std::nextafterf(f, INFINITY);
+    return f > rho ? f : rho;
+}
+// one tile of 32 columns: B operands [64] (lane l = column l&31, K-slots 8(l>>5)..+7) and bounds [32].
+// `s[c] == nullptr`: a column no ray keeps (padding, always-exact list).
+void tube_tile(const rt_sphere *const s[32], float rho, uint4 out_b[64], float out_r[32])
+{
+    for (int c = 0; c < 32; ++c) {
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        out_r[c] = -1.0f;
+        if (s[c]) {
+            out_r[c] = tube_bound(*s[c], rho);
+            if (out_r[c] < INFINITY) {                 // (always-kept columns keep c = 0: h = t, finite)
+                for (int i = 0; i < 3; ++i) {
+                    // two bf16 pieces of the f64 centre: |c - (y1 + y2)| <= 2^-16 |c|
+                    const double ci = s[c]->center[i];
+                    const uint32_t y1 = host_bf16_rne((float)ci);
+                    uint32_t u1 = y1 << 16; float f1; memcpy(&f1, &u1, 4);
+                    const uint32_t y2 = host_bf16_rne((float)(ci - (double)f1));
+                    w[2 * i + 0] = y1 | (y2 << 16);
+                    w[2 * i + 1] = y1 | (y2 << 16);
+                }
+            }
+        }
+        w[6] = rt::kBf16One | (rt::kBf16One << 16);
+        w[7] = rt::kBf16One;
+        out_b[c] = make_uint4(w[0], w[1], w[2], w[3]);
+        out_b[32 + c] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+}
+
 template <int MODE, bool DIAG>
 int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, int *grid_out)
 {
@@ -248,8 +304,8 @@ int rt_create(int32_t device_id, rt_context **out)
     ctx->chunk = env_int("RTIOW_CHUNK", 0);
     ctx->item_block = env_int("RTIOW_ITEM_BLOCK", rt::kItemBlock);
     if (ctx->item_block < 64) ctx->item_block = 64;
-    ctx->scan_mode = env_int("RTIOW_SCAN_MODE", 4);
-    if (ctx->scan_mode < 1 || ctx->scan_mode > 4) ctx->scan_mode = 4;
+    ctx->scan_mode = env_int("RTIOW_SCAN_MODE", 5);
+    if (ctx->scan_mode < 1 || ctx->scan_mode > 5) ctx->scan_mode = 5;
     hipError_t e1 = hipMalloc((void **)&ctx->d_queue, 64);
     hipError_t e2 = hipMalloc((void **)&ctx->d_stats, 256);
     hipError_t e3 = hipEventCreate(&ctx->ev0);
@@ -270,7 +326,7 @@ int rt_destroy(rt_context *ctx)
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     (void)hipFree(ctx->d_filt); (void)hipFree(ctx->d_geo); (void)hipFree(ctx->d_mat);
     (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt); (void)hipFree(ctx->d_bmat16); (void)hipFree(ctx->d_kpt16);
-    (void)hipFree(ctx->d_bmatL);
+    (void)hipFree(ctx->d_bmatL); (void)hipFree(ctx->d_btube); (void)hipFree(ctx->d_rtube);
     (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->d_stage_fix); (void)hipFree(ctx->d_stage_sum); (void)hipFree(ctx->d_stage_rgba);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -299,9 +355,9 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
     RT_HIP(hipDeviceSynchronize());
     (void)hipFree(ctx->d_filt); (void)hipFree(ctx->d_geo); (void)hipFree(ctx->d_mat);
     (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt); (void)hipFree(ctx->d_bmat16); (void)hipFree(ctx->d_kpt16);
-    (void)hipFree(ctx->d_bmatL);
+    (void)hipFree(ctx->d_bmatL); (void)hipFree(ctx->d_btube); (void)hipFree(ctx->d_rtube);
     ctx->d_filt = nullptr; ctx->d_geo = ctx->d_mat = nullptr; ctx->d_bmat = ctx->d_kpt = nullptr;
-    ctx->d_bmat16 = nullptr; ctx->d_kpt16 = nullptr; ctx->d_bmatL = nullptr;
+    ctx->d_bmat16 = nullptr; ctx->d_kpt16 = nullptr; ctx->d_bmatL = nullptr; ctx->d_btube = nullptr; ctx->d_rtube = nullptr;
     ctx->n_spheres = -1;
     const size_t cnt = (size_t)(n > 0 ? n : 1);
     std::vector<float> filt(cnt * 4, 0.0f);
@@ -396,6 +452,26 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
         RT_HIP(hipMalloc((void **)&ctx->d_bmatL, tcnt * 128 * sizeof(uint4)));
         RT_HIP(hipMemcpy(ctx->d_bmatL, bmatL.data(), tcnt * 128 * sizeof(uint4), hipMemcpyHostToDevice));
     }
+    {   // MODE 5 tables
+        const size_t ttc = (size_t)n_tiles / 2 + 1;
+        std::vector<uint4> btube(ttc * 64);
+        std::vector<float> rtube(ttc * 32);
+        std::vector<char> never(n > 0 ? n : 1, 0);
+        for (int e = 0; e < ctx->n_always; ++e) never[ctx->always_idx[e]] = 1;
+        ctx->tube_rho = tube_radius_floor(spheres, n, never.data());
+        for (size_t t = 0; t < ttc; ++t) {
+            const rt_sphere *col[32];
+            for (int c = 0; c < 32; ++c) {
+                const long i = 32 * (long)t + c;
+                col[c] = (i < n && !never[i]) ? &spheres[i] : nullptr;
+            }
+            tube_tile(col, ctx->tube_rho, &btube[t * 64], &rtube[t * 32]);
+        }
+        RT_HIP(hipMalloc((void **)&ctx->d_btube, ttc * 64 * sizeof(uint4)));
+        RT_HIP(hipMalloc((void **)&ctx->d_rtube, ttc * 32 * sizeof(float)));
+        RT_HIP(hipMemcpy(ctx->d_btube, btube.data(), ttc * 64 * sizeof(uint4), hipMemcpyHostToDevice));
+        RT_HIP(hipMemcpy(ctx->d_rtube, rtube.data(), ttc * 32 * sizeof(float), hipMemcpyHostToDevice));
+    }
     RT_HIP(hipMalloc((void **)&ctx->d_bmat16, tcnt * 64 * sizeof(uint4)));
     RT_HIP(hipMalloc((void **)&ctx->d_kpt16, tcnt * 16 * sizeof(float)));
     RT_HIP(hipMemcpy(ctx->d_bmat16, bmat16.data(), tcnt * 64 * sizeof(uint4), hipMemcpyHostToDevice));
@@ -469,6 +545,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.filt = ctx->d_filt; kp.geo = ctx->d_geo; kp.mat = ctx->d_mat;
     kp.bmat = ctx->d_bmat; kp.kpt = ctx->d_kpt; kp.n_tiles = ctx->n_tiles;
     kp.bmat16 = ctx->d_bmat16; kp.kpt16 = ctx->d_kpt16; kp.bmatL = ctx->d_bmatL;
+    kp.btube = ctx->d_btube; kp.rtube = ctx->d_rtube; kp.tube_rho = ctx->tube_rho;
     kp.n_always = ctx->n_always;
     for (int e = 0; e < 8; ++e) kp.always_idx[e] = ctx->always_idx[e];
     kp.fix = (unsigned long long *)d_fix;
@@ -506,7 +583,9 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     case 6: rc = launch_render<3, false>(ctx, kp, stream, &grid); break;
     case 7: rc = launch_render<3, true>(ctx, kp, stream, &grid); break;
     case 8: rc = launch_render<4, false>(ctx, kp, stream, &grid); break;
-    default: rc = launch_render<4, true>(ctx, kp, stream, &grid); break;
+    case 9: rc = launch_render<4, true>(ctx, kp, stream, &grid); break;
+    case 10: rc = launch_render<5, false>(ctx, kp, stream, &grid); break;
+    default: rc = launch_render<5, true>(ctx, kp, stream, &grid); break;
     }
     if (rc) return rc;
     ctx->launched = true;
@@ -695,6 +774,37 @@ int rt_filter_lifted_device(rt_context *ctx, const double *o, const double *d, c
     RT_HIP(hipGetLastError());
     RT_HIP(hipMemcpyAsync(out_D, d_D, 1024 * 4, hipMemcpyDeviceToHost, ctx->own_stream));
     RT_HIP(hipMemcpyAsync(out_R, d_R, 64 * rt::kLiftTerms * 4, hipMemcpyDeviceToHost, ctx->own_stream));
+    RT_HIP(hipStreamSynchronize(ctx->own_stream));
+    return RT_OK;
+}
+
+int rt_filter_tube_device(rt_context *ctx, const double *o, const double *d, const rt_sphere *spheres32,
+                          float *out_h, float *out_rows, float *out_bound, float *out_rho)
+{
+    if (!ctx || !o || !d || !spheres32 || !out_h || !out_rows || !out_bound || !out_rho)
+        return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    RT_HIP(hipSetDevice(ctx->device));
+    const float rho = tube_radius_floor(spheres32, 32, nullptr);
+    *out_rho = rho;
+    const rt_sphere *col[32];
+    for (int c = 0; c < 32; ++c) col[c] = &spheres32[c];
+    uint4 tile[64];
+    tube_tile(col, rho, tile, out_bound);
+    const size_t in_b = 3072 + sizeof(tile), out_b = (64 * 32 * 2 + 64 * 9) * 4;
+    int rc = ensure(&ctx->d_stage_fix, &ctx->stage_fix_bytes, in_b + out_b);
+    if (rc) return rc;
+    char *base = (char *)ctx->d_stage_fix;
+    double *d_o = (double *)base, *d_d = d_o + 192;
+    uint4 *d_tile = (uint4 *)(base + 3072);
+    float *d_h = (float *)(base + in_b), *d_rows = d_h + 64 * 32 * 2;
+    RT_HIP(hipMemcpyAsync(d_o, o, 1536, hipMemcpyHostToDevice, ctx->own_stream));
+    RT_HIP(hipMemcpyAsync(d_d, d, 1536, hipMemcpyHostToDevice, ctx->own_stream));
+    RT_HIP(hipMemcpyAsync(d_tile, tile, sizeof(tile), hipMemcpyHostToDevice, ctx->own_stream));
+    hipLaunchKernelGGL(rt::tube_products_kernel, dim3(1), dim3(64), 0, ctx->own_stream,
+                       (const double *)d_o, (const double *)d_d, (const uint4 *)d_tile, rho, d_h, d_rows);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemcpyAsync(out_h, d_h, 64 * 32 * 2 * 4, hipMemcpyDeviceToHost, ctx->own_stream));
+    RT_HIP(hipMemcpyAsync(out_rows, d_rows, 64 * 9 * 4, hipMemcpyDeviceToHost, ctx->own_stream));
     RT_HIP(hipStreamSynchronize(ctx->own_stream));
     return RT_OK;
 }

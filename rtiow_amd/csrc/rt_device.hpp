@@ -305,4 +305,117 @@ __device__ __forceinline__ void lifted_stage_operands(uint4 *stage, int lane, co
     }
 }
 
+// ---- MODE 5: the tube filter ------------------------------------------------------------------
+// A ray can only hit sphere (c, r) if its LINE passes within r of c, i.e. |(c-o)_perp| <= r.  For any
+// two orthonormal directions u1, u2 perpendicular to the ray that implies |u_k.(c-o)| <= r, k = 1, 2:
+// the sphere lies in a square tube around the line.  Each h_k = u_k.c - u_k.o is LINEAR in c, so its
+// rounding error is relative to |c| and |o|, not to their squares: two bf16 pieces per factor are
+// enough (error ~ 3e-5 |c|, 0.3 % of the book scene's radii; the quadratic forms of modes 1-4 need
+// three pieces and still carry a slack of 6e-5 (|o|^2+|c|^2)).  Per (ray, direction) row and
+// per-sphere column the 16 K-slots of one v_mfma_f32_32x32x16_bf16 are
+//
+//   slots 4i .. 4i+3 (i = x,y,z):  A (x1,x1,x2,x2)  B (y1,y2,y1,y2)   = (x1+x2)(y1+y2)
+//   slots 12,13,14:                A (t1,t2,t3)     B (1,1,1)         t = -(u_k.o), split exactly
+//   slot 15:                       zero
+//
+// and one instruction evaluates 16 rays x 2 directions against 32 spheres.  Soundness:
+// with the basis errors (|u_k.d^| <= 64u, ||u_k|-1| <= 64u, measured <= 8u), the operand truncation
+// (2^-16 per factor) and the accumulation (charged 2u per add on sum|terms|),
+//     hit  =>  |h_k| <= R + e,   R = r (1+64u) + 640u |c|   (per sphere),   e = 128u |o|   (per ray).
+// The per-ray part is folded into the rows: they are scaled by lambda = rho / (rho + e), which makes
+// lambda |h_k| <= max(R, rho) for every sphere (rho: a per-scene radius floor chosen on the host).
+constexpr float kTubeBasisErr = 64.0f * kUnitRoundoff;
+constexpr float kTubeCenterErr = 640.0f * kUnitRoundoff;
+constexpr float kTubeOriginErr = 128.0f * kUnitRoundoff;
+
+struct TubeRay {
+    float u[2][3];      // lambda * u_k
+    float t[2];         // -(lambda u_k) . o
+    bool sane;          // false: outside the analysed range, every sphere must be tested exactly
+};
+
+__device__ __forceinline__ TubeRay make_tube(D3 o, D3 d, float rho)
+{
+    TubeRay T;
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    const float a = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+    const float s = __builtin_amdgcn_rsqf(a);
+    const float gx = dx * s, gy = dy * s, gz = dz * s;
+    // orthonormal basis without a branch or a singular direction (Duff et al., JCGT 2017)
+    const float sg = __builtin_copysignf(1.0f, gz);
+    const float aa = -__builtin_amdgcn_rcpf(sg + gz);
+    const float b = gx * gy * aa;
+    const float lam = rho * __builtin_amdgcn_rcpf(__builtin_fmaf(kTubeOriginErr, __builtin_sqrtf(oo), rho));
+    T.u[0][0] = lam * __builtin_fmaf(sg * gx, gx * aa, 1.0f);
+    T.u[0][1] = lam * (sg * b);
+    T.u[0][2] = lam * (-sg * gx);
+    T.u[1][0] = lam * b;
+    T.u[1][1] = lam * __builtin_fmaf(gy, gy * aa, sg);
+    T.u[1][2] = lam * (-gy);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        T.t[k] = -__builtin_fmaf(T.u[k][2], oz, __builtin_fmaf(T.u[k][1], oy, T.u[k][0] * ox));
+    T.sane = (a > 1e-20f) && (a < 1e20f) && (oo < 1e30f);
+    if (!T.sane) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { T.u[k][0] = T.u[k][1] = T.u[k][2] = 0.0f; T.t[k] = 3.0e38f; }
+    }
+    return T;
+}
+// a lane without a ray: |h| is huge for every column
+__device__ __forceinline__ TubeRay no_tube_ray()
+{
+    TubeRay T;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { T.u[k][0] = T.u[k][1] = T.u[k][2] = 0.0f; T.t[k] = 3.0e38f; }
+    T.sane = true;
+    return T;
+}
+
+// the two rows of a ray as 2 x 8 dwords (two bf16 each, low half = even K-slot)
+__device__ __forceinline__ void tube_a_words(const TubeRay &T, uint32_t (&w)[2][8])
+{
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float x = T.u[k][i];
+            const uint32_t p1 = (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)x);
+            const float r1 = x - __uint_as_float(p1 << 16);
+            const uint32_t p2 = (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)r1);
+            w[k][2 * i + 0] = p1 | (p1 << 16);
+            w[k][2 * i + 1] = p2 | (p2 << 16);
+        }
+        const Bf3 t = split_bf16x3_hw(T.t[k]);
+        w[k][6] = t.p1 | (t.p2 << 16);
+        w[k][7] = t.p3;
+    }
+}
+
+// Per-ray dwords -> MFMA A operands through LDS (4 KB for the wave's 64 rays, one round).  For
+// v_mfma_f32_32x32x16_bf16 lane l holds row l&31 and K-slots 8(l>>5) .. +7; rows are laid out so
+// that a result lane owns BOTH directions of its rays: row 8b + x (x = 0..7) = ray 8(b>>1) + x,
+// direction b&1.  The 16-byte quarter q = 2 dir + khalf of ray r sits at r*4 + (q ^ ((r>>1)&3)):
+// conflict-free for the writers (one ray per lane) and the readers (8 consecutive rays per quarter).
+__device__ __forceinline__ void tube_stage_operands(uint4 *stage, int lane, const uint32_t (&w)[2][8], bf16x8 (&A)[4])
+{
+    const int sw = (lane >> 1) & 3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = q >> 1, kh = q & 1;
+        stage[lane * 4 + (q ^ sw)] = make_uint4(w[k][4 * kh], w[k][4 * kh + 1], w[k][4 * kh + 2], w[k][4 * kh + 3]);
+    }
+    __builtin_amdgcn_wave_barrier();                // LDS ops of one wave execute in order
+    const int row = lane & 31, kh = lane >> 5;
+    const int q = 2 * ((row >> 3) & 1) + kh;
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+        const int ray = 16 * G + 8 * (row >> 4) + (row & 7);
+        A[G] = __builtin_bit_cast(bf16x8, stage[ray * 4 + (q ^ ((ray >> 1) & 3))]);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 } // namespace rt

@@ -51,6 +51,9 @@ struct KParams {
     const uint4 *bmat16;       // [tiles][64] bf16x3 B operand: 8 bf16 (y1,y2,y1,y3,y2,y1,y3,y2) of S[k][sphere]
     const float *kpt16;        // [tiles][16] K' for the bf16x3 form (larger KU)
     const uint4 *bmatL;        // [tiles][2][64] MODE 4 B operands: the 64 K-slots of the lifted form (rt_device.hpp)
+    const uint4 *btube;        // [tiles/2 + 1][64] MODE 5 B operands: 32 spheres x 16 K-slots (rt_device.hpp)
+    const float *rtube;        // [tiles/2 + 1][32] MODE 5 per-sphere bound max(R, rho); negative: never kept
+    float tube_rho;            // MODE 5 radius floor
     int32_t n_tiles;
     int32_t n_always;          // spheres that skip the filter and are always tested exactly
     int32_t always_idx[8];
@@ -84,6 +87,9 @@ __device__ __forceinline__ D3 ld3(const double *p) { return mk(p[0], p[1], p[2])
 // MODE 4: the filter as ONE contraction of 11 per-ray terms with 11 per-sphere terms (rt_device.hpp,
 //         "lifted" form) on the bf16 matrix pipe, two chained K = 32 MFMAs per 16 rays x 16 spheres:
 //         the VALU no longer squares and subtracts, it only looks at the sign of the result.
+// MODE 5: the tube filter: |u_k.(c-o)| <= r for two directions u_1, u_2 perpendicular to the ray, linear
+//         in c, so two bf16 pieces per factor suffice: ONE v_mfma_f32_32x32x16_bf16 tests 16 rays
+//         (both directions) against 32 spheres -- a third of the matrix-pipe time of modes 3/4.
 constexpr int kRowPad = 80;         // floats per row of the ray-operand transpose buffer
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -98,13 +104,20 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
     __shared__ uint16_t cand[MODE == 1 ? kCandCap : 1][kBlock];     // MODE 1: per-lane candidate lists
     constexpr bool MATRIX = (MODE >= 2);
     constexpr bool LIFTED = (MODE == 4);
-    __shared__ float s_rayop[(MATRIX && !LIFTED) ? kBlock / 64 : 1][(MATRIX && !LIFTED) ? 8 : 1][(MATRIX && !LIFTED) ? kRowPad : 1];
+    constexpr bool TUBE = (MODE == 5);
+    constexpr bool RAYOP = (MODE == 2 || MODE == 3);
+    __shared__ float s_rayop[RAYOP ? kBlock / 64 : 1][RAYOP ? 8 : 1][RAYOP ? kRowPad : 1];
     // per ray, one bit per sphere of the current segment (kSegTiles tiles): set by whichever lane
     // holds the passing result (ds_or, nothing returned, nothing waited for), read by the owner
     // (MODE 4: the same LDS first carries the per-ray operand dwords to the MFMA layout)
     static_assert((kSegTiles / 2) * 64 * sizeof(unsigned int) >= 32 * kStageStride * sizeof(uint4), "operand staging fits the bitmap");
+    static_assert((kSegTiles / 2) * 64 * sizeof(unsigned int) >= 64 * 4 * sizeof(uint4), "tube operand staging fits the bitmap");
     __shared__ __attribute__((aligned(16))) unsigned int s_bits[MATRIX ? kBlock / 64 : 1][MATRIX ? kSegTiles / 2 : 1][MATRIX ? 64 : 1];
     __shared__ unsigned int s_sum[MATRIX ? kBlock : 1];     // per ray: which of its bitmap words are non-zero
+    // pooled exact tests: ring of waiting (ray << 16 | sphere) pairs per wave; per-ray minimum root and its sphere
+    __shared__ unsigned int s_pool[MATRIX ? kBlock / 64 : 1][MATRIX ? 128 : 1];
+    __shared__ unsigned long long s_best[MATRIX ? kBlock : 1];
+    __shared__ unsigned int s_bidx[MATRIX ? kBlock : 1];
     // the item's running sums (exact u64 fixed point) live in LDS, not in 6 VGPRs: they are touched
     // once per finished sample, and registers are what the 4th wave per SIMD is paid with
     __shared__ unsigned long long s_acc[3][kBlock];
@@ -343,15 +356,78 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                     }
                 }
             };
-            // The owner walks its candidates straight off the bitmap, in ascending sphere order:
-            // `summary` says which words are non-zero, `word` holds the bits left in the current
-            // one.  Trip count = the longest candidate list in the wave.
-            auto walk_bitmap = [&](int seg0) {
-                unsigned summary = s_sum[tid], word = 0u;
+            // ---- candidates -> exact tests, pooled over the wave -------------------------
+            // A ray has 1.1 candidates on average but the longest list in a wave has 5-6, and the
+            // exact test is ~80 f64 instructions: testing list entry k of every lane together would
+            // run the test 5-6 times per bounce at ~20 % lane use.  Instead the owners only ENUMERATE
+            // their bitmaps into a per-wave ring of (ray, sphere) pairs, and whenever 64 pairs are
+            // waiting each lane takes ONE pair: it fetches that ray's (o, d) from the owner lane
+            // (ds_bpermute), computes the root with the reference's own f64 operations, and the
+            // per-ray minimum is taken in LDS on an order-preserving u64 image of the f64 root
+            // (ds_min_u64); equal roots resolve to the larger sphere index (ds_max_u32), the same
+            // rule as exact_test().  The ring persists across bitmap segments.
+            auto f64_key = [](double x) -> unsigned long long {         // total order of f64 as u64
+                const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+                return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+            };
+            auto key_f64 = [](unsigned long long k) -> double {
+                return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
+            };
+            auto from_lane_f64 = [](int byte_addr, double x) -> double {
+                const long long b = __double_as_longlong(x);
+                const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(b & 0xFFFFFFFFll));
+                const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(b >> 32));
+                return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+            };
+            unsigned int *pool_w = &s_pool[wave][0];
+            unsigned long long *best_w = &s_best[wave * 64];
+            unsigned int *bidx_w = &s_bidx[wave * 64];
+            best_w[lane] = 0xFFF0000000000000ull;                       // f64_key(+inf): closest = infinity
+            bidx_w[lane] = 0u;                                          // sphere index + 1; 0 = none
+            uint32_t pool_n = 0, pool_done = 0;                         // wave-uniform
+            auto pool_round = [&]() {
+                RT_COUNT(5);
+                const uint32_t e_i = pool_done + (uint32_t)lane;
+                const bool act = e_i < pool_n;
+                const uint32_t e = act ? pool_w[e_i & 127u] : ((uint32_t)lane << 16);
+                const int r = (int)(e >> 16), idx = (int)(e & 0xFFFFu);
+                const int src = r << 2;
+                const D3 ro = mk(from_lane_f64(src, o.x), from_lane_f64(src, o.y), from_lane_f64(src, o.z));
+                const D3 rd = mk(from_lane_f64(src, d.x), from_lane_f64(src, d.y), from_lane_f64(src, d.z));
+                if (act) {
+                    if (DIAG) n_cand++;
+                    // sphere.rs:16-34, exactly as exact_test() computes it
+                    const double4 g = *reinterpret_cast<const double4 *>(geo + 4 * (size_t)idx);
+                    const double ra = length_squared(rd);
+                    const D3 oc = ro - mk(g.x, g.y, g.z);
+                    const double half_b = dot(oc, rd);
+                    const double c = length_squared(oc) - g.w;
+                    const double disc = half_b * half_b - ra * c;
+                    if (!(disc < 0.0) && !(half_b > 0.0 && c > 0.0)) {
+                        if (DIAG) n_roots++;
+                        const double sqrtd = __builtin_sqrt(disc);
+                        double root = (-half_b - sqrtd) / ra;
+                        if (root < t_min) root = (-half_b + sqrtd) / ra;
+                        if (!(root < t_min)) {
+                            // (a NaN root maps above +inf and never wins, as in exact_test(); -0 -> +0)
+                            const unsigned long long key = f64_key(root + 0.0);
+                            const unsigned long long old = atomicMin(&best_w[r], key);
+                            if (old > key) bidx_w[r] = 0u;              // a new minimum: forget the old index
+                            if (best_w[r] == key) atomicMax(&bidx_w[r], (unsigned)idx + 1u);
+                        }
+                    }
+                }
+                pool_done = min(pool_done + 64u, pool_n);
+            };
+            // owners push the candidates of segment seg0 (ascending sphere order); rounds run as the ring fills
+            auto enumerate = [&](int seg0) {
+                unsigned summary = alive ? s_sum[tid] : 0u, word = 0u;
                 int wbase = 0;
-                while (__any((summary | word) != 0u)) {
-                    RT_COUNT(5);
-                    if ((summary | word) != 0u) {
+                for (;;) {
+                    const bool has = (summary | word) != 0u;
+                    const unsigned long long m = __ballot(has);
+                    if (m == 0ull) break;
+                    if (has) {
                         if (word == 0u) {
                             const int w = __builtin_ctz(summary);
                             summary &= summary - 1u;
@@ -360,14 +436,135 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                         }
                         const int bpos = __builtin_ctz(word);
                         word &= word - 1u;
-                        if (DIAG) n_cand++;
-                        exact_test(wbase + bpos);
+                        const uint32_t pos = pool_n + (uint32_t)__popcll(m & lane_lt);
+                        pool_w[pos & 127u] = ((uint32_t)lane << 16) | (uint32_t)(wbase + bpos);
                     }
+                    pool_n += (uint32_t)__popcll(m);
+                    if (pool_n - pool_done >= 64u) pool_round();
+                }
+            };
+            // after the last segment: drain the ring, then every owner takes its minimum
+            auto finish_pool = [&]() {
+                while (pool_done < pool_n) pool_round();
+                const unsigned int hb = bidx_w[lane];
+                if (alive && hb != 0u) {
+                    const double root = key_f64(best_w[lane]);
+                    const int idx = (int)hb - 1;
+                    if (root < closest || (root == closest && idx > hit)) { closest = root; hit = idx; }
                 }
             };
             const int nt = P.n_tiles;                   // even; the tables hold nt + 2 tiles
 
-            if constexpr (LIFTED) {
+            if constexpr (TUBE) {
+                const TubeRay T = alive ? make_tube(o, d, P.tube_rho) : no_tube_ray();
+                bf16x8 A[4];
+                {
+                    uint32_t w[2][8];
+                    tube_a_words(T, w);
+                    tube_stage_operands(reinterpret_cast<uint4 *>(bits_w), lane, w, A);
+                }
+                if (alive) {
+                    for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e]); }
+                    // outside the analysed range: everything is tested exactly
+                    if (!T.sane) for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i); }
+                }
+                typedef float f32x16 __attribute__((ext_vector_type(16)));
+                const int ntt = nt >> 1;                    // tiles of 32 spheres; the tables hold ntt + 1
+                const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<uint4 *>(P.btube), 0, (ntt + 1) * 1024, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(P.rtube), 0, (ntt + 1) * 128, 0x00020000);
+                const int voff = lane * 16, roff = (lane & 31) * 4;
+                auto load_b = [&](int t32) -> bf16x8 {
+                    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, voff, t32 * 1024, 0));
+                };
+                auto load_r = [&](int t32) -> float {
+                    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, roff, t32 * 128, 0));
+                };
+                const int col32 = lane & 31, hh = lane >> 5;
+                const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                // results of one MFMA: acc[8bb + j] / acc[8bb + 4 + j] are h_1 / h_2 of ray 16G + 8bb + 4hh + j
+                // against sphere 32 t + col32; kept iff max(|h_1|, |h_2|) <= bound
+                auto look_tube = [&](int G, const f32x16 &acc, float bound, int wrel) {
+                    // max(|h_1|, |h_2|) in ONE instruction each (source modifiers take the magnitudes); written
+                    // as asm because fmaxf() would first canonicalise both inputs.  The FIRST pair stays in
+                    // C++: the compiler inserts the matrix-pipe -> VALU wait states in front of that read
+                    // (it does not see into asm), and every asm statement is ordered behind it by `tok`.
+                    // The results are non-negative floats, which order like integers (v_min3_i32).
+                    int m[2][4];
+                    m[0][0] = __float_as_int(__builtin_fmaxf(__builtin_fabsf(acc[0]), __builtin_fabsf(acc[4])));
+                    const int tok = m[0][0];
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (bb + j > 0)
+                                asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(m[bb][j]) : "v"(acc[8 * bb + j]), "v"(acc[8 * bb + 4 + j]), "v"(tok));
+                    const int n01 = min(min(m[0][0], m[0][1]), m[0][2]);
+                    const int n02 = min(min(n01, m[0][3]), m[1][0]);
+                    const int n03 = min(min(n02, m[1][1]), m[1][2]);
+                    const float nall = __int_as_float(min(n03, m[1][3]));
+                    if (__builtin_expect(__ballot(nall <= bound) != 0ull, 0)) {
+                        RT_COUNT(3);
+                        int colv = col32;
+                        asm volatile("" : "+v"(colv));              // keep the address arithmetic on this side of the branch
+                        const unsigned bit = 1u << colv;
+                        const unsigned wbit = 1u << wrel;
+                        unsigned int *row = bits_w + wrel * 64;
+#pragma unroll
+                        for (int bb = 0; bb < 2; ++bb) {
+                            const float nG = __int_as_float(min(min(m[bb][0], m[bb][1]), min(m[bb][2], m[bb][3])));
+                            if (__ballot(nG <= bound) != 0ull) {
+                                RT_COUNT(4);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (__int_as_float(m[bb][j]) <= bound) {
+                                        const int ray = 16 * G + 8 * bb + 4 * hh + j;
+                                        atomicOr(&row[ray], bit);
+                                        atomicOr(&sum_w[ray], wbit);
+                                    }
+                            }
+                        }
+                    }
+                };
+                RT_STAMP(5);
+                for (int seg0 = 0; seg0 < nt; seg0 += kSegTiles) {
+                    const int seg_n = min(kSegTiles, nt - seg0);
+                    const int nwords = seg_n >> 1;                  // one bitmap word per 32-sphere tile
+                    for (int w = 0; w < nwords; ++w) bits_w[w * 64 + lane] = 0u;
+                    s_sum[tid] = 0u;
+                    __builtin_amdgcn_wave_barrier();
+                    const int t0 = seg0 >> 1;
+                    // one 32-sphere tile: four independent MFMAs (one per 16-ray group); two results in
+                    // flight so the matrix pipe works on the next group while the VALU looks at this one
+                    auto do_tile = [&](int w, const bf16x8 &b, float bound) {
+                        RT_COUNT(7);
+                        f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], b, zero16, 0, 0, 0);
+                        f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], b, zero16, 0, 0, 0);
+                        look_tube(0, acc0, bound, w);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], b, zero16, 0, 0, 0);
+                        look_tube(1, acc1, bound, w);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[3], b, zero16, 0, 0, 0);
+                        look_tube(2, acc0, bound, w);
+                        look_tube(3, acc1, bound, w);
+                    };
+                    // B operands and bounds ping-pong between two register sets, each fetched a tile ahead
+                    bf16x8 bp = load_b(t0), bq;
+                    float rp = load_r(t0), rq;
+                    int w = 0;
+                    for (; w + 1 < nwords; w += 2) {
+                        bq = load_b(t0 + w + 1); rq = load_r(t0 + w + 1);
+                        do_tile(w, bp, rp);
+                        bp = load_b(t0 + w + 2); rp = load_r(t0 + w + 2);
+                        do_tile(w + 1, bq, rq);
+                    }
+                    if (w < nwords) do_tile(w, bp, rp);
+                    __builtin_amdgcn_wave_barrier();
+                    RT_STAMP(6);
+                    enumerate(seg0);
+                }
+                finish_pool();
+            } else if constexpr (LIFTED) {
                 const LiftedRay L = alive ? make_lifted(o, d) : no_lifted_ray();
                 bf16x8 A[4][2];
                 {
@@ -420,8 +617,9 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                     }
                     __builtin_amdgcn_wave_barrier();
                     RT_STAMP(6);
-                    if (alive) walk_bitmap(seg0);
+                    enumerate(seg0);
                 }
+                finish_pool();
             } else {
             RayFilter f;
             if (alive) {
@@ -503,8 +701,9 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                 }
                 __builtin_amdgcn_wave_barrier();
                 RT_STAMP(6);
-                if (alive) walk_bitmap(seg0);
+                enumerate(seg0);
             }
+            finish_pool();
             }
         }
         RT_STAMP(2);
@@ -566,6 +765,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
             bool front = false;
             D3 p = o, nrm = mk(0.0, 0.0, 0.0), sp = mk(0.0, 0.0, 0.0), albedo = mk(1.0, 1.0, 1.0);
             double param = 0.0, inv_param = 0.0, r0_front = 0.0, r0_back = 0.0;
+            uint32_t w_first = 0u;
             if (is_hit) {
                 const double *mrec = mat + kMatStride * (size_t)hit;
                 const double4 g = *reinterpret_cast<const double4 *>(geo + 4 * (size_t)hit);
@@ -580,13 +780,20 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                 const D3 outward = (p - mk(g.x, g.y, g.z)) * mA.x;               // / radius = * (1/radius)
                 front = dot(d, outward) < 0.0;
                 nrm = front ? outward : (mk(0.0, 0.0, 0.0) - outward);
+                // One Philox block for every lane with a hit: the first unit-sphere try of a
+                // Lambertian/Metal lane, and -- computed ahead, consumed (ev++) only if the draw is
+                // really made -- the Dialectric's reflectance draw.  One wave-level call, not two.
+                U4 w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
+                w_first = w.x;
                 if (kind != RT_KIND_DIALECTRIC) {
-                    do {                                                         // vec3.rs:37-45
+                    ev++;
+                    sp = mk(u11(w.x), u11(w.y), u11(w.z));
+                    while (!(length_squared(sp) < 1.0)) {                        // vec3.rs:37-45
                         RT_COUNT(6);
-                        const U4 w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
+                        w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
                         ev++;
                         sp = mk(u11(w.x), u11(w.y), u11(w.z));
-                    } while (!(length_squared(sp) < 1.0));
+                    }
                 } else {
                     const double2 mD = *reinterpret_cast<const double2 *>(mrec + 6);  // 1/ir, r0(1/ir)
                     const double2 mE = *reinterpret_cast<const double2 *>(mrec + 8);  // r0(ir), -
@@ -628,9 +835,8 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                         const double x = 1.0 - cos_theta;
                         const double x2 = x * x;
                         const double refl = r0 + (1.0 - r0) * ((x2 * x2) * x);   // materials.rs:80
-                        const U4 w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
-                        ev++;
-                        do_refract = refl <= u01(w.x);
+                        ev++;                                                    // the block drawn above
+                        do_refract = refl <= u01(w_first);
                     }
                     ndir = do_refract ? refract(uV, nrm, ratio) : reflect(uV, nrm);
                 }
@@ -787,6 +993,36 @@ __global__ __launch_bounds__(64) void lifted_products_kernel(const double *o, co
         f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[G][0], b0, zero, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[G][1], b1, acc, 0, 0, 0);
         for (int i = 0; i < 4; ++i) D_out[(16 * G + 4 * quad + i) * 16 + col] = acc[i];
+    }
+}
+
+// One tile of the MODE 5 (tube) filter exactly as the render kernel evaluates it: 64 rays against
+// the 32 columns of `tile`.  h_out[ray][column][k] = lambda u_k.(c - o) as the matrix pipe returns it;
+// rows_out[ray] = (lambda u_1, lambda u_2, t_1, t_2, sane).
+__global__ __launch_bounds__(64) void tube_products_kernel(const double *o, const double *d, const uint4 *tile, float rho,
+                                                         float *h_out, float *rows_out)
+{
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    __shared__ uint4 stage[64 * 4];
+    const int lane = threadIdx.x, col = lane & 31, hh = lane >> 5;
+    const TubeRay T = make_tube(mk(o[3 * lane], o[3 * lane + 1], o[3 * lane + 2]),
+                                mk(d[3 * lane], d[3 * lane + 1], d[3 * lane + 2]), rho);
+    for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) rows_out[lane * 9 + 3 * k + i] = T.u[k][i];
+    rows_out[lane * 9 + 6] = T.t[0]; rows_out[lane * 9 + 7] = T.t[1]; rows_out[lane * 9 + 8] = T.sane ? 1.0f : 0.0f;
+    bf16x8 A[4];
+    uint32_t w[2][8];
+    tube_a_words(T, w);
+    tube_stage_operands(stage, lane, w, A);
+    const bf16x8 b = __builtin_bit_cast(bf16x8, tile[lane]);
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int G = 0; G < 4; ++G) {
+        const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[G], b, zero16, 0, 0, 0);
+        for (int bb = 0; bb < 2; ++bb)
+            for (int j = 0; j < 4; ++j) {
+                const int ray = 16 * G + 8 * bb + 4 * hh + j;
+                h_out[(ray * 32 + col) * 2 + 0] = acc[8 * bb + j];
+                h_out[(ray * 32 + col) * 2 + 1] = acc[8 * bb + 4 + j];
+            }
     }
 }
 

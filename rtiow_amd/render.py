@@ -165,6 +165,25 @@ class Renderer:
                                                      Cc.ctypes.data_as(C.c_void_p)), "rt_filter_lifted_device")
         return D, R, Cc
 
+    def filter_tube(self, o, d, spheres32):
+        """One tile of the tube filter (the shipped scan mode), as the kernel evaluates it.
+
+        o, d: (64, 3) f64 rays; spheres32: structured array (SPHERE_DTYPE) of 32 spheres.
+        Returns h (64, 32, 2) f32, rows (64, 9) f32, bound (32,) f32, rho."""
+        o = np.ascontiguousarray(o, dtype=np.float64).reshape(64, 3)
+        d = np.ascontiguousarray(d, dtype=np.float64).reshape(64, 3)
+        sp = np.ascontiguousarray(spheres32)
+        assert sp.shape == (32,) and sp.dtype.itemsize == C.sizeof(_ffi.rt_sphere)
+        h = np.zeros((64, 32, 2), dtype=np.float32)
+        rows = np.zeros((64, 9), dtype=np.float32)
+        bound = np.zeros(32, dtype=np.float32)
+        rho = C.c_float(0.0)
+        _ffi.check(self._lib.rt_filter_tube_device(self._h, o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
+                                                   sp.ctypes.data_as(C.POINTER(_ffi.rt_sphere)),
+                                                   h.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p),
+                                                   bound.ctypes.data_as(C.c_void_p), C.byref(rho)), "rt_filter_tube_device")
+        return h, rows, bound, float(rho.value)
+
     def philox(self, ctr, key):
         c = (C.c_uint32 * 4)(*ctr)
         k = (C.c_uint32 * 2)(*key)

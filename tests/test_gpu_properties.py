@@ -129,12 +129,12 @@ def test_gpu_reproduces_the_reference_png_sky_rows(renderer, book1_flat):
 
 
 def test_all_scan_filters_give_the_same_bits(book1_flat, cfg2):
-    """The four filter implementations (VALU + scalar loads, f32 MFMA, bf16x3 MFMA, single-contraction
-    bf16x3 MFMA) are four ways of discarding spheres the reference cannot hit: the frame must not
-    depend on which runs."""
+    """The five filter implementations (VALU + scalar loads, f32 MFMA, bf16x3 MFMA, single-contraction
+    bf16x3 MFMA, bf16x2 tube) are five ways of discarding spheres the reference cannot hit: the frame
+    must not depend on which runs."""
     w, h, spp, fix, st = cfg2
     cands, roots = {}, set()
-    for mode in ("1", "2", "3", "4"):
+    for mode in ("1", "2", "3", "4", "5"):
         os.environ["RTIOW_SCAN_MODE"] = mode
         try:
             r = rt.Renderer(0)
@@ -150,6 +150,7 @@ def test_all_scan_filters_give_the_same_bits(book1_flat, cfg2):
     assert len(roots) == 1                                  # the exact path sees the same real hits
     assert cands["1"] <= cands["2"] * 1.2 and cands["2"] <= cands["3"] * 1.01   # looser KU keeps more
     assert cands["4"] <= cands["3"] * 1.05                  # same KU, same slack: about as selective
+    assert cands["5"] <= cands["3"] * 1.25                  # a square tube instead of a slack-inflated cylinder
 
 
 def test_tenk_scene_full_size_properties(renderer):
