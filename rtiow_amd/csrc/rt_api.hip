@@ -88,6 +88,8 @@ int validate_params(const rt_params *p)
     if (!p) return fail(RT_ERR_INVALID_ARGUMENT, "params is NULL");
     if (p->width < 2 || p->height < 2)
         return fail(RT_ERR_INVALID_ARGUMENT, "width and height must be >= 2 (u,v divide by W-1,H-1; main.rs:131-132)");
+    if (p->width > 65535 || p->height > 65535)
+        return fail(RT_ERR_INVALID_ARGUMENT, "width and height must be <= 65535");
     if ((long long)p->width * p->height > 0x7fffffffLL)
         return fail(RT_ERR_INVALID_ARGUMENT, "width*height does not fit the 32-bit Philox pixel counter");
     if (p->spp < 0 || p->sample_begin < 0 || (long long)p->spp + p->sample_begin > 0x7fffffffLL)

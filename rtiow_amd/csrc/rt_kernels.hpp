@@ -121,11 +121,16 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
     // the item's running sums (exact u64 fixed point) live in LDS, not in 6 VGPRs: they are touched
     // once per finished sample, and registers are what the 4th wave per SIMD is paid with
     __shared__ unsigned long long s_acc[3][kBlock];
+    // so does the path throughput (contract C3): read and written once per bounce
+    __shared__ double s_thr[3][kBlock];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     s_acc[0][tid] = 0ull; s_acc[1][tid] = 0ull; s_acc[2][tid] = 0ull;    // own slots only: no barrier needed
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    // number of set bits of a wave mask below this lane (v_mbcnt: no per-lane 64-bit mask to keep)
+    auto rank_below = [](unsigned long long m) -> uint32_t {
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    };
 
     // The filter table is read-only for the whole launch and indexed by a
     // wave-uniform counter: reading it through the constant address space makes
@@ -142,11 +147,11 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
     bool has_item = false, dead = false, alive = false;
     uint32_t pix_local = 0, pix_global = 0;
     int s = 0, s_end = 0;
-    uint32_t px_i = 0, px_j = 0;
-    D3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1, 1, 1);
+    uint32_t px_ij = 0;                            // pixel column | row << 16 (rt_params: both < 65536)
+    D3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     int depth = 0;
     uint32_t ev = 0;
-    uint32_t n_rays = 0, n_samples = 0;
+    uint32_t n_rays = 0, n_samples = 0;            // wave totals (uniform)
     unsigned long long tot_cand = 0, tot_roots = 0;     // wave totals (uniform)
     uint32_t wave_next = 0, wave_end = 0;          // this wave's reserved block of work items (uniform)
 
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                     newbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(newbase, leader));
                 }
                 if (want) {
-                    const uint32_t r = (uint32_t)__popcll(m & lane_lt);
+                    const uint32_t r = rank_below(m);
                     const uint32_t w = (r < avail) ? wave_next + r : newbase + (r - avail);
                     if (w < P.total_items) {
                         const uint32_t c = w / P.npix;
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                         const uint32_t j = (lt * (uint32_t)P.shard_count + (uint32_t)P.shard_index) * (uint32_t)P.tile_rows
                                            + (rr - lt * (uint32_t)P.tile_rows);
                         pix_global = j * (uint32_t)P.width + i;
-                        px_i = i; px_j = j;
+                        px_ij = i | (j << 16);
                         s = P.sample_begin + (int)c * P.chunk;
                         s_end = min(s + P.chunk, P.sample_begin + P.spp);
                         has_item = true;
@@ -217,8 +222,8 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
             RT_COUNT(1);
             U4 w = philox4x32_10(pix_global, (uint32_t)s, 0u, 0u, P.k0, P.k1);
             ev = 1u;
-            const double u = ((double)px_i + u01(w.x)) / wm1;       // main.rs:131
-            const double v = ((double)px_j + u01(w.y)) / hm1;       // main.rs:132
+            const double u = ((double)(px_ij & 0xFFFFu) + u01(w.x)) / wm1;   // main.rs:131
+            const double v = ((double)(px_ij >> 16) + u01(w.y)) / hm1;       // main.rs:132
             double lx = u11(w.z), ly = u11(w.w);
             while (!(length_squared(mk(lx, ly, 0.0)) < 1.0)) {      // vec3.rs:59-68
                 RT_COUNT(2);
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
             const D3 offset = ld3(P.cam.u) * rd.x + ld3(P.cam.v) * rd.y;
             o = cam_origin + offset;
             d = (((ld3(P.cam.llc) + ld3(P.cam.horizontal) * u) + ld3(P.cam.vertical) * v) - cam_origin) - offset;
-            thr = mk(1.0, 1.0, 1.0);
+            s_thr[0][tid] = 1.0; s_thr[1][tid] = 1.0; s_thr[2][tid] = 1.0;
             depth = P.max_depth;
             alive = true;
         }
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                         }
                         const int bpos = __builtin_ctz(word);
                         word &= word - 1u;
-                        const uint32_t pos = pool_n + (uint32_t)__popcll(m & lane_lt);
+                        const uint32_t pos = pool_n + rank_below(m);
                         pool_w[pos & 127u] = ((uint32_t)lane << 16) | (uint32_t)(wbase + bpos);
                     }
                     pool_n += (uint32_t)__popcll(m);
@@ -539,12 +544,18 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                     // flight so the matrix pipe works on the next group while the VALU looks at this one
                     auto do_tile = [&](int w, const bf16x8 &b, float bound) {
                         RT_COUNT(7);
+                        // (the empty asm pins the issue order: the scheduler would otherwise sink each MFMA
+                        //  below the previous look to share registers, and the wave would sit out the full
+                        //  matrix-pipe latency four times per tile)
                         f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], b, zero16, 0, 0, 0);
                         f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], b, zero16, 0, 0, 0);
+                        asm volatile("" : "+v"(acc1));
                         look_tube(0, acc0, bound, w);
                         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], b, zero16, 0, 0, 0);
+                        asm volatile("" : "+v"(acc0));
                         look_tube(1, acc1, bound, w);
                         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[3], b, zero16, 0, 0, 0);
+                        asm volatile("" : "+v"(acc1));
                         look_tube(2, acc0, bound, w);
                         look_tube(3, acc1, bound, w);
                     };
@@ -757,6 +768,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
         }
         RT_STAMP(3);
         // ---- (e) shade: main.rs:44-56 + materials.rs ----------------------------
+        bool finished = false;                                          // this lane's sample ended in this pass
         if (alive) {
             bool done = false;
             D3 L = mk(0.0, 0.0, 0.0);
@@ -810,7 +822,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
             if (!is_hit) {
                 const double t = 0.5 * (uV.y + 1.0);                             // main.rs:54-55
                 const D3 sky = mk(1.0, 1.0, 1.0) * (1.0 - t) + mk(0.5, 0.7, 1.0) * t;
-                L = thr * sky;                                                   // contract C3
+                L = mk(s_thr[0][tid], s_thr[1][tid], s_thr[2][tid]) * sky;       // contract C3
                 done = true;
             } else {
                 D3 ndir;
@@ -840,7 +852,11 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                     }
                     ndir = do_refract ? refract(uV, nrm, ratio) : reflect(uV, nrm);
                 }
-                thr = thr * albedo;                                              // (1,1,1) for Dialectric
+                if (kind != RT_KIND_DIALECTRIC) {                                // Dialectric: (1,1,1), x * 1.0 == x
+                    s_thr[0][tid] = s_thr[0][tid] * albedo.x;
+                    s_thr[1][tid] = s_thr[1][tid] * albedo.y;
+                    s_thr[2][tid] = s_thr[2][tid] * albedo.z;
+                }
                 o = p;
                 d = ndir;
                 depth -= 1;
@@ -851,7 +867,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                 const unsigned long long a1 = s_acc[1][tid] + quantize(L.y);
                 const unsigned long long a2 = s_acc[2][tid] + quantize(L.z);
                 alive = false;
-                n_samples++;
+                finished = true;
                 s++;
                 if (s >= s_end) {
                     unsigned long long *px = P.fix + (size_t)pix_local * 3u;
@@ -863,6 +879,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                 }
             }
         }
+        n_samples += (uint32_t)__popcll(__ballot(finished));
         RT_STAMP(4);
     }
 
@@ -874,13 +891,10 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
     if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(P.stats + 8 + k, (unsigned long long)s_cnt[tid >> 6][k]);
 #endif
     {
-        unsigned long long ns = n_samples;
         const unsigned long long nc = tot_cand, nr = tot_roots;
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) ns += __shfl_xor(ns, sh);
         if (lane == 0) {
             atomicAdd(P.stats + 0, (unsigned long long)n_rays);
-            atomicAdd(P.stats + 1, ns);
+            atomicAdd(P.stats + 1, (unsigned long long)n_samples);
             atomicAdd(P.stats + 2, nc);
             atomicAdd(P.stats + 3, nr);
         }
