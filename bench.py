@@ -144,6 +144,7 @@ def main():
             st = renderer.last_stats()                 # waits for this launch's events only
             kernel_ms.append(st["kernel_ms"])
             rays, samples = st["rays_traced"], st["samples"]
+            step.scan_mode = st["scan_mode"]
 
     def fence():
         torch.cuda.synchronize()
@@ -152,6 +153,7 @@ def main():
             torch.cuda.synchronize()
 
     step.last_full = None
+    step.scan_mode = -1
 
     for _ in range(args.warmup):
         step(False)
@@ -206,7 +208,7 @@ def main():
                 "frame_crc32": frame_crc,      # of the exact sums: equal for equal (W, H, spp) at any N
             },
             "roofline": {
-                "bound": "valu", "kernel": "rt::render_kernel<3>",
+                "bound": "valu", "kernel": f"rt::render_kernel<{step.scan_mode}, false>",
                 "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4),
                 "traffic": traffic,

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RTIOW_HIP_ABI_VERSION 1
+#define RTIOW_HIP_ABI_VERSION 2
 
 typedef struct rt_context rt_context;
 
@@ -119,6 +119,8 @@ typedef struct {
     float    kernel_ms;          /* render kernel, HIP events on its stream         */
     int32_t  n_spheres;
     int32_t  grid_blocks, block_threads;
+    int32_t  scan_mode;          /* sphere-scan filter that ran: 0 none (RT_FLAG_NO_FILTER), 1..5 */
+    int32_t  reserved;
 } rt_stats;
 
 /* ---- lifetime -------------------------------------------------------------- */

@@ -575,6 +575,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     int grid = 0;
     const bool diag = (p->flags & RT_FLAG_DIAG_STATS) != 0;
     const int mode = (p->flags & RT_FLAG_NO_FILTER) ? 0 : ctx->scan_mode;
+    ctx->last.scan_mode = mode;
     switch (mode * 2 + (diag ? 1 : 0)) {
     case 0: rc = launch_render<0, false>(ctx, kp, stream, &grid); break;
     case 1: rc = launch_render<0, true>(ctx, kp, stream, &grid); break;

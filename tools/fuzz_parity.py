@@ -43,5 +43,5 @@ for case in range(cases):
     if not ok:
         bad += 1
         print(f"MISMATCH case {case}: n={len(flat)} {W}x{H}x{spp} spread={spread:.2f} diff px={int(np.count_nonzero((fix != fb).any(2)))}", flush=True)
-print(f"{cases} cases, {bad} mismatches, {tot_rays} rays, mode {os.environ.get('RTIOW_SCAN_MODE', '3 (default)')}, {time.time() - t0:.1f} s", flush=True)
+print(f"{cases} cases, {bad} mismatches, {tot_rays} rays, mode {os.environ.get('RTIOW_SCAN_MODE', '5 (default)')}, {time.time() - t0:.1f} s", flush=True)
 sys.exit(1 if bad else 0)
