@@ -492,19 +492,17 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                 // against sphere 32 t + col32; kept iff max(|h_1|, |h_2|) <= bound
                 auto look_tube = [&](int G, const f32x16 &acc, float bound, int wrel) {
                     // max(|h_1|, |h_2|) in ONE instruction each (source modifiers take the magnitudes); written
-                    // as asm because fmaxf() would first canonicalise both inputs.  The FIRST pair stays in
-                    // C++: the compiler inserts the matrix-pipe -> VALU wait states in front of that read
-                    // (it does not see into asm), and every asm statement is ordered behind it by `tok`.
-                    // The results are non-negative floats, which order like integers (v_min3_i32).
+                    // as asm because fmaxf() would first canonicalise both inputs.  The compiler does not see
+                    // into asm, so one ordinary instruction reads the result first (`tok`): the matrix-pipe ->
+                    // VALU wait states are inserted in front of THAT read, and every asm statement is ordered
+                    // behind it.  The results are non-negative floats, which order like integers (v_min3_i32).
                     int m[2][4];
-                    m[0][0] = __float_as_int(__builtin_fmaxf(__builtin_fabsf(acc[0]), __builtin_fabsf(acc[4])));
-                    const int tok = m[0][0];
+                    const int tok = __float_as_int(acc[0]) & 0x7FFFFFFF;
 #pragma unroll
                     for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            if (bb + j > 0)
-                                asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(m[bb][j]) : "v"(acc[8 * bb + j]), "v"(acc[8 * bb + 4 + j]), "v"(tok));
+                            asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(m[bb][j]) : "v"(acc[8 * bb + j]), "v"(acc[8 * bb + 4 + j]), "v"(tok));
                     const int n01 = min(min(m[0][0], m[0][1]), m[0][2]);
                     const int n02 = min(min(n01, m[0][3]), m[1][0]);
                     const int n03 = min(min(n02, m[1][1]), m[1][2]);
