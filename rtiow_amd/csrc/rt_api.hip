@@ -78,6 +78,7 @@ struct rt_context {
     void *d_stage_rgba = nullptr; size_t stage_rgba_bytes = 0;
     int blocks_per_cu = 0;     // 0 = occupancy query
     int chunk = 0;             // 0 = default
+    int tail_spp = -1;         // samples per pixel handed out one per item at the end; -1 = automatic
     int item_block = rt::kItemBlock;
 };
 
@@ -304,6 +305,7 @@ int rt_create(int32_t device_id, rt_context **out)
     ctx->cu_count = prop.multiProcessorCount;
     ctx->blocks_per_cu = env_int("RTIOW_BLOCKS_PER_CU", 0);
     ctx->chunk = env_int("RTIOW_CHUNK", 0);
+    ctx->tail_spp = env_int("RTIOW_TAIL_SPP", -1);
     ctx->item_block = env_int("RTIOW_ITEM_BLOCK", rt::kItemBlock);
     if (ctx->item_block < 64) ctx->item_block = 64;
     ctx->scan_mode = env_int("RTIOW_SCAN_MODE", 5);
@@ -529,8 +531,25 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     // item count fits 31 bits
     int chunk = ctx->chunk > 0 ? ctx->chunk : 4;
     if (chunk > p->spp) chunk = p->spp > 0 ? p->spp : 1;
-    while (npix * (((long long)p->spp + chunk - 1) / chunk) > 0x7fffffffLL) chunk *= 2;
-    const long long nchunks = p->spp > 0 ? ((long long)p->spp + chunk - 1) / chunk : 0;
+    // The last samples of every pixel are handed out ONE per item, after all the chunked items.  The
+    // launch ends when the slowest wave ends; a wave that reserved one of the last blocks of 4-sample
+    // items is ~40 bounces behind one that found the queue empty.  Measured on cfg2 (tools/exit_times.py):
+    // without this phase the average wave idles through the last 8.4 % of the launch, with ~48 single
+    // samples per resident lane 3.1 % (what is left is the longest path of the last samples).
+    // RTIOW_TAIL_SPP overrides.
+    long long tail_spp = ctx->tail_spp;
+    if (tail_spp < 0) {
+        const long long lanes = (long long)ctx->cu_count * 4 * rt::kBlock;      // 4 workgroups per CU stay resident
+        tail_spp = npix > 0 ? (48 * lanes + npix - 1) / npix : 0;
+    }
+    if (tail_spp > p->spp) tail_spp = p->spp;
+    if (chunk <= 1) tail_spp = 0;
+    long long bulk_spp = (long long)p->spp - tail_spp;
+    auto n_items = [&](int ch) { return npix * ((bulk_spp + ch - 1) / ch + tail_spp); };
+    while (n_items(chunk) > 0x7fffffffLL) {
+        if (tail_spp > 0) { tail_spp = 0; bulk_spp = p->spp; } else chunk *= 2;
+    }
+    const long long nchunks = (bulk_spp + chunk - 1) / chunk;
 
     rt::KParams kp;
     memset(&kp, 0, sizeof(kp));
@@ -543,7 +562,8 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.tile_rows = p->tile_rows; kp.shard_index = p->shard_index; kp.shard_count = p->shard_count;
     kp.rows = rows; kp.n_spheres = ctx->n_spheres; kp.chunk = chunk;
     kp.item_block = ctx->item_block;
-    kp.npix = (uint32_t)npix; kp.total_items = (uint32_t)(npix * nchunks);
+    kp.npix = (uint32_t)npix; kp.total_items = (uint32_t)(npix * (nchunks + tail_spp));
+    kp.bulk_items = (uint32_t)(npix * nchunks); kp.bulk_spp = (int32_t)bulk_spp;
     kp.filt = ctx->d_filt; kp.geo = ctx->d_geo; kp.mat = ctx->d_mat;
     kp.bmat = ctx->d_bmat; kp.kpt = ctx->d_kpt; kp.n_tiles = ctx->n_tiles;
     kp.bmat16 = ctx->d_bmat16; kp.kpt16 = ctx->d_kpt16; kp.bmatL = ctx->d_bmatL;
@@ -616,7 +636,7 @@ int rt_last_stats(rt_context *ctx, rt_stats *stats)
     return RT_OK;
 }
 
-#if defined(RT_PHASE_STAMPS) || defined(RT_BLOCK_COUNTS)
+#if defined(RT_PHASE_STAMPS) || defined(RT_BLOCK_COUNTS) || defined(RT_EXIT_TIMES)
 extern "C" int rt_debug_phase_cycles(rt_context *ctx, unsigned long long out[8])
 {
     RT_HIP(hipSetDevice(ctx->device));

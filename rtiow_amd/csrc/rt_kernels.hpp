@@ -44,7 +44,9 @@ struct KParams {
     int32_t chunk;             // samples per work item
     int32_t item_block;        // work items a wave reserves per atomic (>= 64)
     uint32_t npix;             // rows * width
-    uint32_t total_items;      // npix * ceil(spp / chunk)
+    uint32_t total_items;      // bulk_items + npix * (spp - bulk_spp)
+    uint32_t bulk_items;       // npix * ceil(bulk_spp / chunk): items of `chunk` samples; the rest are single samples
+    int32_t bulk_spp;          // samples per pixel covered by the chunked items
     const float *filt;         // [n][4]  f32 filter record (cx, cy, cz, K')
     const float *bmat;         // [tiles][64] MFMA B operand: lane l -> S[k=l>>4][sphere 16t+(l&15)], S=(cx,cy,cz,1)
     const float *kpt;          // [tiles][16] K' per sphere (NaN: never kept by the filter)
@@ -162,6 +164,10 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
 #define RT_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); \
                          __builtin_amdgcn_s_waitcnt(0); ph[k] += tn_ - tprev; tprev = tn_; } while (0)
 #define RT_COUNT(k) do { } while (0)
+#elif defined(RT_EXIT_TIMES)
+    const unsigned long long t_wave_start = __builtin_amdgcn_s_memrealtime();
+#define RT_STAMP(k) do { } while (0)
+#define RT_COUNT(k) do { } while (0)
 #elif defined(RT_BLOCK_COUNTS)
     // Diagnostic build only: wave-level execution counts of the main blocks, into stats[8..15].
     __shared__ unsigned int s_cnt[kBlock / 64][8];
@@ -195,8 +201,11 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                     const uint32_t r = rank_below(m);
                     const uint32_t w = (r < avail) ? wave_next + r : newbase + (r - avail);
                     if (w < P.total_items) {
-                        const uint32_t c = w / P.npix;
-                        pix_local = w - c * P.npix;
+                        // items [0, bulk_items): (chunk c, pixel), chunk-major; then one sample per item
+                        const bool single = w >= P.bulk_items;
+                        const uint32_t wr = single ? w - P.bulk_items : w;
+                        const uint32_t c = wr / P.npix;
+                        pix_local = wr - c * P.npix;
                         const uint32_t rr = pix_local / (uint32_t)P.width;
                         const uint32_t i = pix_local - rr * (uint32_t)P.width;
                         const uint32_t lt = rr / (uint32_t)P.tile_rows;            // local tile
@@ -204,8 +213,8 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                                            + (rr - lt * (uint32_t)P.tile_rows);
                         pix_global = j * (uint32_t)P.width + i;
                         px_ij = i | (j << 16);
-                        s = P.sample_begin + (int)c * P.chunk;
-                        s_end = min(s + P.chunk, P.sample_begin + P.spp);
+                        s = P.sample_begin + (single ? P.bulk_spp + (int)c : (int)c * P.chunk);
+                        s_end = single ? s + 1 : min(s + P.chunk, P.sample_begin + P.bulk_spp);
                         has_item = true;
                     } else {
                         dead = true;
@@ -883,7 +892,14 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
 
         // (end of the bounce loop body is stamped at the top of the next iteration as phase 4)
     // wave totals -> device counters
-#if defined(RT_PHASE_STAMPS)
+#if defined(RT_EXIT_TIMES)
+    // Diagnostic build only: when (100 MHz real-time clock) the first/last/average wave leaves the kernel
+    if (lane == 0) {
+        const unsigned long long te = __builtin_amdgcn_s_memrealtime();
+        atomicMax(P.stats + 8, te); atomicMax(P.stats + 9, ~te); atomicAdd(P.stats + 10, te);
+        atomicMax(P.stats + 11, ~t_wave_start); atomicAdd(P.stats + 12, 1ull);
+    }
+#elif defined(RT_PHASE_STAMPS)
     if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(P.stats + 8 + k, ph[k]);
 #elif defined(RT_BLOCK_COUNTS)
     if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(P.stats + 8 + k, (unsigned long long)s_cnt[tid >> 6][k]);
