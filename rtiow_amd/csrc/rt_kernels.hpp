@@ -497,6 +497,9 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                 };
                 const int col32 = lane & 31, hh = lane >> 5;
                 const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                // which 16-ray groups hold at least one path (wave-uniform)
+                const unsigned groups = ((alive_mask & 0xFFFFull) ? 1u : 0u) | ((alive_mask & 0xFFFF0000ull) ? 2u : 0u) |
+                                        ((alive_mask & 0xFFFF00000000ull) ? 4u : 0u) | ((alive_mask >> 48) ? 8u : 0u);
                 // results of one MFMA: acc[8bb + j] / acc[8bb + 4 + j] are h_1 / h_2 of ray 16G + 8bb + 4hh + j
                 // against sphere 32 t + col32; kept iff max(|h_1|, |h_2|) <= bound
                 auto look_tube = [&](int G, const f32x16 &acc, float bound, int wrel) {
@@ -566,17 +569,33 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
                         look_tube(2, acc0, bound, w);
                         look_tube(3, acc1, bound, w);
                     };
-                    // B operands and bounds ping-pong between two register sets, each fetched a tile ahead
-                    bf16x8 bp = load_b(t0), bq;
-                    float rp = load_r(t0), rq;
-                    int w = 0;
-                    for (; w + 1 < nwords; w += 2) {
-                        bq = load_b(t0 + w + 1); rq = load_r(t0 + w + 1);
-                        do_tile(w, bp, rp);
-                        bp = load_b(t0 + w + 2); rp = load_r(t0 + w + 2);
-                        do_tile(w + 1, bq, rq);
+                    if (__builtin_expect(groups == 0xFu, 1)) {
+                        // B operands and bounds ping-pong between two register sets, each fetched a tile ahead
+                        bf16x8 bp = load_b(t0), bq;
+                        float rp = load_r(t0), rq;
+                        int w = 0;
+                        for (; w + 1 < nwords; w += 2) {
+                            bq = load_b(t0 + w + 1); rq = load_r(t0 + w + 1);
+                            do_tile(w, bp, rp);
+                            bp = load_b(t0 + w + 2); rp = load_r(t0 + w + 2);
+                            do_tile(w + 1, bq, rq);
+                        }
+                        if (w < nwords) do_tile(w, bp, rp);
+                    } else {
+                        // end of the launch: some 16-ray groups of this wave have no path left (no more work
+                        // items); only the groups with a ray go through the matrix pipe and the look
+                        for (int w = 0; w < nwords; ++w) {
+                            RT_COUNT(7);
+                            const bf16x8 b = load_b(t0 + w);
+                            const float bound = load_r(t0 + w);
+#pragma unroll
+                            for (int G = 0; G < 4; ++G)
+                                if (groups & (1u << G)) {
+                                    const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[G], b, zero16, 0, 0, 0);
+                                    look_tube(G, acc, bound, w);
+                                }
+                        }
                     }
-                    if (w < nwords) do_tile(w, bp, rp);
                     __builtin_amdgcn_wave_barrier();
                     RT_STAMP(6);
                     enumerate(seg0);
