@@ -7,18 +7,20 @@
 //     LANE owns one path at a time and never waits for its neighbours -- when
 //     its path ends it immediately starts its next pixel-sample ("path
 //     regeneration"), so the sphere scan always runs with full waves;
-//   * work = items (pixel, chunk of <= `chunk` consecutive samples); a wave
+//   * work = items (pixel, chunk of <= `chunk` consecutive samples), then the last
+//     samples of every pixel one per item (a short end of the launch); a wave
 //     reserves a block of items with ONE returning atomic on a device-wide
-//     counter and deals them to its idle lanes (__ballot + popcount + prefix rank);
+//     counter and deals them to its idle lanes (__ballot + popcount + v_mbcnt rank);
 //   * the sphere scan (HittableList::hit, mod.rs:54-70) decides nothing: it is a
 //     conservative FILTER (rt_device.hpp) -- it may send a sphere to the exact
 //     test needlessly, never drop one the reference would hit.  The shipped form
-//     (MODE 3) evaluates it on the bf16 matrix pipe, 16 rays x 16 spheres per
-//     instruction; MODE 1 (VALU + scalar loads) and MODE 2 (f32 matrix pipe) are
-//     kept as cross-checks, MODE 0 has no filter at all;
-//   * spheres the filter keeps are marked in per-ray LDS bitmaps and then go
-//     through the reference's exact f64 test (sphere.rs:16-34), so every hit
-//     decision and every shading value is the reference's own f64 arithmetic;
+//     (MODE 5, the tube filter) evaluates it on the bf16 matrix pipe, 16 rays x 2
+//     directions x 32 spheres per instruction; MODEs 1-4 (VALU + scalar loads, f32
+//     matrix pipe, two quadratic forms on the bf16 matrix pipe) are kept as
+//     cross-checks, MODE 0 has no filter at all;
+//   * spheres the filter keeps are marked in per-ray LDS bitmaps, pooled over the
+//     wave and put through the reference's exact f64 test (sphere.rs:16-34), so every
+//     hit decision and every shading value is the reference's own f64 arithmetic;
 //   * per-lane radiance sums are exact u64 fixed point (contract C5) and are
 //     added to the frame buffer with 64-bit atomics once per item.
 #pragma once
