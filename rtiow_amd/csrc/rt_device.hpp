@@ -64,6 +64,10 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
 {
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
     constexpr uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    // The key is wave-uniform, and so are the ten round keys: the compiler would compute them once
+    // per kernel and keep 20 SGPRs alive across the whole bounce loop (and spill others to make room).
+    // Making the key opaque here has every call rebuild them with 18 scalar adds instead.
+    asm volatile("" : "+s"(k0), "+s"(k1));
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)M0 * c0;      // hi and lo of one 32x32 product
