@@ -91,7 +91,7 @@ def main():
 
     import torch
     import rtiow_amd as rt
-    from rtiow_amd.distributed import gather_frame, shard_row_map
+    from rtiow_amd.distributed import FrameGatherer, shard_row_map
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -126,17 +126,19 @@ def main():
     d_fix = torch.zeros((len(rows), W, 3), dtype=torch.int64, device=dev)
     d_rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
     stream = torch.cuda.current_stream().cuda_stream
+    rehearse = args.rehearse_on_one_gpu and world > 1
+    gather = FrameGatherer(H, W, args.tile_rows, rank, world, "cpu" if rehearse else dev)
 
     kernel_ms, rays, samples = [], 0, 0
 
     def step(record):
         nonlocal rays, samples
         renderer.render_device(cam, params, d_fix.data_ptr(), stream)
-        if args.rehearse_on_one_gpu and world > 1:
-            full = gather_frame(d_fix.cpu(), H, args.tile_rows, rank, world)
+        if rehearse:
+            full = gather(d_fix.cpu())
             full = full.to(dev) if rank == 0 else None
         else:
-            full = gather_frame(d_fix, H, args.tile_rows, rank, world)
+            full = gather(d_fix)
         if rank == 0:
             renderer.resolve_rgba8_device(full.data_ptr(), W, H, spp_frame, 1, d_rgba.data_ptr(), stream)
             step.last_full = full

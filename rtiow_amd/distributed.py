@@ -30,27 +30,43 @@ def max_shard_rows(height, tile_rows, shard_count):
     return max(len(shard_row_map(height, tile_rows, k, shard_count)) for k in range(shard_count))
 
 
+class FrameGatherer:
+    """The gather of one frame geometry, with every buffer and row-index tensor allocated once:
+    per frame it costs one copy into the padded send buffer, ONE torch.distributed.gather, and one
+    index_copy per rank on `dst` (no host-side work in the loop other than launching those)."""
+
+    def __init__(self, height, width, tile_rows, rank, world, device, dst=0, group=None):
+        import torch
+        self.height, self.width, self.tile_rows = int(height), int(width), int(tile_rows)
+        self.rank, self.world, self.dst, self.group = int(rank), int(world), int(dst), group
+        self.rows_local = len(shard_row_map(height, tile_rows, rank, world))
+        pad_rows = max_shard_rows(height, tile_rows, world)
+        self.padded = torch.zeros((pad_rows, width, 3), dtype=torch.int64, device=device)
+        self.parts = self.full = self.idx = None
+        if rank == dst:
+            self.parts = [self.padded] if world == 1 else [torch.empty_like(self.padded) for _ in range(world)]
+            self.full = torch.empty((height, width, 3), dtype=torch.int64, device=device)
+            self.idx = [torch.as_tensor(shard_row_map(height, tile_rows, k, world), device=device) for k in range(world)]
+
+    def __call__(self, local_fix):
+        """local_fix: int64 [rows_k, W, 3] (the u64 bit patterns of this rank's exact sums).
+        Returns the full [H, W, 3] frame on rank `dst` (a buffer reused by the next call), None elsewhere."""
+        import torch.distributed as dist
+        assert local_fix.shape[0] == self.rows_local and local_fix.shape[1] == self.width
+        self.padded[: self.rows_local].copy_(local_fix)
+        if self.world > 1:
+            dist.gather(self.padded, gather_list=self.parts, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        for k in range(self.world):
+            self.full.index_copy_(0, self.idx[k], self.parts[k][: self.idx[k].shape[0]])
+        return self.full
+
+
 def gather_frame(local_fix, height, tile_rows, rank, world, dst=0, group=None):
     """local_fix: torch int64 tensor [rows_k, W, 3] holding this rank's exact sums
     (the u64 bit patterns).  Returns the full [H, W, 3] frame on rank `dst`, None
-    elsewhere.  One collective: torch.distributed.gather of equally padded tiles."""
-    import torch
-    import torch.distributed as dist
-
-    width = local_fix.shape[1]
-    pad_rows = max_shard_rows(height, tile_rows, world)
-    padded = torch.zeros((pad_rows, width, 3), dtype=torch.int64, device=local_fix.device)
-    padded[: local_fix.shape[0]] = local_fix
-    if world == 1:
-        parts = [padded]
-    else:
-        parts = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-        dist.gather(padded, gather_list=parts, dst=dst, group=group)
-    if rank != dst:
-        return None
-    full = torch.empty((height, width, 3), dtype=torch.int64, device=local_fix.device)
-    for k in range(world):
-        rows = shard_row_map(height, tile_rows, k, world)
-        idx = torch.as_tensor(rows, device=local_fix.device)
-        full.index_copy_(0, idx, parts[k][: len(rows)])
-    return full
+    elsewhere.  One collective: torch.distributed.gather of equally padded tiles.
+    (One-shot form of FrameGatherer.)"""
+    g = FrameGatherer(height, local_fix.shape[1], tile_rows, rank, world, local_fix.device, dst=dst, group=group)
+    return g(local_fix)

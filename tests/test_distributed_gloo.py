@@ -26,7 +26,7 @@ def _worker(rank, world, port, tile_rows, w, h, spp, out_path):
     import torch.distributed as dist
     import oracle
     import rtiow_amd as rt
-    from rtiow_amd.distributed import gather_frame, shard_row_map
+    from rtiow_amd.distributed import FrameGatherer, gather_frame, shard_row_map
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     flat = rt.random_scene(1).flatten()
