@@ -40,8 +40,13 @@ def _worker(rank, world, port, tile_rows, w, h, spp, out_path):
         parts.append(fix)
     local = np.concatenate(parts, axis=0) if parts else np.zeros((0, w, 3), dtype=np.uint64)
     full = gather_frame(torch.from_numpy(local.view(np.int64).copy()), h, tile_rows, rank, world)
+    # the preallocated form bench.py uses, called twice with different data: its buffers are reused
+    g = FrameGatherer(h, w, tile_rows, rank, world, "cpu")
+    twice = g(torch.from_numpy((local + np.uint64(1)).view(np.int64).copy()))
+    again = g(torch.from_numpy(local.view(np.int64).copy()))
     dist.barrier()
     if rank == 0:
+        assert twice is again and torch.equal(again, full)
         np.save(out_path, full.numpy().view(np.uint64))
     dist.destroy_process_group()
 
