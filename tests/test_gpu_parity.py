@@ -164,6 +164,11 @@ def test_errors(renderer, book1_flat):
         nan["center"][2, 0] = np.inf
         with pytest.raises(rt.RtiowHipError, match="finite"):
             fresh.upload_scene(nan)
+        fresh.upload_scene(book1_flat)
+        with pytest.raises(rt.RtiowHipError, match="65535"):
+            fresh.render(rt.book1_camera(70000, 2), rt.make_params(70000, 2, 1))
+        with pytest.raises(rt.RtiowHipError, match="t_min"):
+            fresh.render(rt.book1_camera(8, 8), rt.make_params(8, 8, 1, t_min=0.0))
     finally:
         fresh.close()
     with pytest.raises(rt.RtiowHipError, match="device_id"):

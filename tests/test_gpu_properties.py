@@ -29,6 +29,7 @@ def test_cfg2_accounting(cfg2, book1_flat):
     assert st["samples"] == w * h * spp
     assert 2.4 < st["rays_traced"] / st["samples"] < 2.9
     assert st["sphere_tests"] == st["rays_traced"] * len(book1_flat)
+    assert st["scan_mode"] == int(os.environ.get("RTIOW_SCAN_MODE", "5"))     # the tube filter unless overridden
     mean = fix.astype(np.float64) / 2.0 ** 32 / spp
     assert 0.0 <= mean.min() and mean.max() <= 1.0 + 1e-12          # sky <= 1 and albedos <= 1
     assert 0.3 < mean.mean() < 0.6
@@ -93,9 +94,12 @@ def test_cfg2_device_buffers_accumulate_flag(renderer, book1_flat, cfg2):
 
 
 def test_work_decomposition_does_not_change_results(book1_flat, cfg2):
-    """Samples per work item and blocks per CU are scheduling knobs only."""
+    """Samples per work item, the single-sample phase at the end of the launch, items per reservation
+    and blocks per CU are scheduling knobs only."""
     w, h, spp, fix, st = cfg2
-    for env in ({"RTIOW_CHUNK": "1"}, {"RTIOW_CHUNK": "7", "RTIOW_BLOCKS_PER_CU": "2"}, {"RTIOW_CHUNK": "100"}):
+    for env in ({"RTIOW_CHUNK": "1"}, {"RTIOW_CHUNK": "7", "RTIOW_BLOCKS_PER_CU": "2"}, {"RTIOW_CHUNK": "100"},
+                {"RTIOW_TAIL_SPP": "0"}, {"RTIOW_TAIL_SPP": "3", "RTIOW_CHUNK": "5"},
+                {"RTIOW_TAIL_SPP": "1000000", "RTIOW_ITEM_BLOCK": "64"}, {"RTIOW_TAIL_SPP": "37", "RTIOW_ITEM_BLOCK": "1000"}):
         os.environ.update(env)
         try:
             r = rt.Renderer(0)
