@@ -34,6 +34,7 @@ import numpy as np  # noqa: E402
 
 PEAK_FP32_VECTOR_TFLOPS = 157.3        # MI355X_MICROARCH.md, "Peak FP32 (vector)"
 PEAK_HBM_GBPS = 8000.0                 # MI355X_MICROARCH.md, HBM3E spec peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md, dense bf16 matrix peak
 FLOP_PER_TEST = 17                     # per ray-sphere test
 FLOP_PER_RAY_FIXED = 65                # hit finalisation + shading per ray
 
@@ -178,15 +179,18 @@ def main():
         flops = rays * (FLOP_PER_TEST * n_sph + FLOP_PER_RAY_FIXED)        # this rank's launch
         achieved = flops / (k_ms * 1e-3) / 1e12
         algo_bytes = len(rows) * W * 12 + n_sph * 36
-        traffic = None
+        # counters of the same launch configuration from the committed rocprofv3 --pmc passes (profiles/)
+        traffic = mfma_insts = valu_busy = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
                 if j.get("config") == [W, H, spp_frame, world]:
                     traffic = j.get("hbm_bytes_per_launch")
+                    mfma_insts = j.get("mfma_insts_per_launch")
+                    valu_busy = j.get("valu_busy")
             except Exception:
-                traffic = None
+                traffic = mfma_insts = valu_busy = None
         frame_crc = None
         if step.last_full is not None:
             import zlib
@@ -216,6 +220,11 @@ def main():
                 "traffic": traffic,
                 "kernel_ms": round(k_ms, 3), "launches_timed": len(kernel_ms),
                 "algorithmic_flop_per_launch": flops,
+                # the matrix pipe's own view: v_mfma_f32_32x32x16_bf16 = 32768 flop each, against the dense bf16 peak
+                "mfma": (None if mfma_insts is None else
+                         {"achieved_TFLOPs": round(mfma_insts * 32768 / (k_ms * 1e-3) / 1e12, 1), "peak_TFLOPs": PEAK_BF16_MFMA_TFLOPS,
+                          "frac": round(mfma_insts * 32768 / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}),
+                "valu_busy": None if valu_busy is None else round(valu_busy, 3),
                 "hbm": {"algorithmic_bytes_per_launch": algo_bytes,
                         "achieved_GBps": round(algo_bytes / (k_ms * 1e-3) / 1e9, 4),
                         "peak_GBps": PEAK_HBM_GBPS,

@@ -32,6 +32,9 @@ if "GRBM_GUI_ACTIVE" in pm:
     out["effective_clock_GHz"] = pm["GRBM_GUI_ACTIVE"] / 8 / avg_ns
 json.dump(out, open(os.path.join(root, "profiles", f"{tag}_rocprofv3.json"), "w"), indent=1)
 json.dump({"config": [1200, 675, 100, 1], "hbm_bytes_per_launch": fetch + write,
+           "mfma_insts_per_launch": pm.get("SQ_INSTS_MFMA"), "valu_insts_per_launch": pm.get("SQ_INSTS_VALU"),
+           "valu_busy": (pm["SQ_ACTIVE_INST_VALU"] * 4.0 / (pm["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+                         if "SQ_ACTIVE_INST_VALU" in pm and "GRBM_GUI_ACTIVE" in pm else None),
            "source": f"profiles/{tag}_rocprofv3.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"},
           open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out["kernel_stats"][0]), out["hbm_bytes_per_launch"], out.get("effective_clock_GHz"))
