@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RTIOW_HIP_ABI_VERSION 2
+#define RTIOW_HIP_ABI_VERSION 3
 
 typedef struct rt_context rt_context;
 
@@ -121,6 +121,8 @@ typedef struct {
     int32_t  grid_blocks, block_threads;
     int32_t  scan_mode;          /* sphere-scan filter that ran: 0 none (RT_FLAG_NO_FILTER), 1..5 */
     int32_t  reserved;
+    uint64_t live_per_bounce[64]; /* rays traced at bounce index k (0 = camera ray; indices >= 63 share the
+                                    last slot); sums to rays_traced (RT_FLAG_DIAG_STATS, else 0) */
 } rt_stats;
 
 /* ---- lifetime -------------------------------------------------------------- */

@@ -311,7 +311,7 @@ int rt_create(int32_t device_id, rt_context **out)
     ctx->scan_mode = env_int("RTIOW_SCAN_MODE", 5);
     if (ctx->scan_mode < 1 || ctx->scan_mode > 5) ctx->scan_mode = 5;
     hipError_t e1 = hipMalloc((void **)&ctx->d_queue, 64);
-    hipError_t e2 = hipMalloc((void **)&ctx->d_stats, 256);
+    hipError_t e2 = hipMalloc((void **)&ctx->d_stats, 1024);
     hipError_t e3 = hipEventCreate(&ctx->ev0);
     hipError_t e4 = hipEventCreate(&ctx->ev1);
     hipError_t e5 = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
@@ -576,7 +576,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     if (!(p->flags & RT_FLAG_ACCUMULATE) && npix > 0)
         RT_HIP(hipMemsetAsync(d_fix, 0, (size_t)npix * 3 * sizeof(unsigned long long), stream));
     RT_HIP(hipMemsetAsync(ctx->d_queue, 0, 64, stream));
-    RT_HIP(hipMemsetAsync(ctx->d_stats, 0, 256, stream));
+    RT_HIP(hipMemsetAsync(ctx->d_stats, 0, 1024, stream));
 
     memset(&ctx->last, 0, sizeof(ctx->last));
     ctx->last.n_spheres = ctx->n_spheres;
@@ -624,8 +624,9 @@ int rt_last_stats(rt_context *ctx, rt_stats *stats)
     RT_HIP(hipEventSynchronize(ctx->ev1));
     float ms = 0.0f;
     RT_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    unsigned long long h[4] = { 0, 0, 0, 0 };
+    unsigned long long h[80];
     RT_HIP(hipMemcpy(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 64; ++k) ctx->last.live_per_bounce[k] = h[16 + k];
     ctx->last.rays_traced = h[0];
     ctx->last.samples = h[1] + ctx->zero_depth_samples;
     ctx->last.candidates = h[2];

@@ -65,7 +65,7 @@ struct KParams {
     const double *mat;         // [n][10] exact (1/r, param, albedo rgb, kind, 1/param, r0(1/ir), r0(ir), -)
     unsigned long long *fix;   // [rows][width][3] exact sums
     unsigned int *queue;       // work counter
-    unsigned long long *stats; // [0] rays [1] samples [2] candidates [3] exact roots
+    unsigned long long *stats; // [0] rays [1] samples [2] candidates [3] exact roots [8..15] diagnostic builds [16..79] rays per bounce index (DIAG)
 };
 
 constexpr int RT_KIND_LAMBERTIAN = 0, RT_KIND_METAL = 1, RT_KIND_DIALECTRIC = 2;
@@ -125,12 +125,14 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
     // the item's running sums (exact u64 fixed point) live in LDS, not in 6 VGPRs: they are touched
     // once per finished sample, and registers are what the 4th wave per SIMD is paid with
     __shared__ unsigned long long s_acc[3][kBlock];
+    __shared__ unsigned int s_live[DIAG ? kBlock / 64 : 1][DIAG ? 64 : 1];    // DIAG: rays per bounce index, per wave
     // so does the path throughput (contract C3): read and written once per bounce
     __shared__ double s_thr[3][kBlock];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     s_acc[0][tid] = 0ull; s_acc[1][tid] = 0ull; s_acc[2][tid] = 0ull;    // own slots only: no barrier needed
+    if (DIAG) s_live[tid >> 6][tid & 63] = 0u;                          // this wave's row only
     // number of set bits of a wave mask below this lane (v_mbcnt: no per-lane 64-bit mask to keep)
     auto rank_below = [](unsigned long long m) -> uint32_t {
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -257,6 +259,8 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
         const unsigned long long alive_mask = __ballot(alive);
         if (alive_mask == 0ull) break;
         n_rays += (uint32_t)__popcll(alive_mask);
+        // DIAG: rays traced per bounce index (0 = camera ray), per wave in LDS, flushed at exit
+        if (DIAG && alive) atomicAdd(&s_live[tid >> 6][min(P.max_depth - depth, 63)], 1u);
 
         // ---- (d) HittableList::hit, mod.rs:54-70 -------------------------------
         double closest = __builtin_inf();
@@ -927,6 +931,10 @@ __global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(con
 #endif
     {
         const unsigned long long nc = tot_cand, nr = tot_roots;
+        if (DIAG) {
+            const unsigned int nl = s_live[tid >> 6][lane];
+            if (nl) atomicAdd(P.stats + 16 + lane, (unsigned long long)nl);
+        }
         if (lane == 0) {
             atomicAdd(P.stats + 0, (unsigned long long)n_rays);
             atomicAdd(P.stats + 1, (unsigned long long)n_samples);

@@ -39,7 +39,11 @@ def shard_row_indices(params):
 
 
 def stats_dict(st):
-    return {k: getattr(st, k) for k, _ in _ffi.rt_stats._fields_}
+    out = {}
+    for k, _ in _ffi.rt_stats._fields_:
+        v = getattr(st, k)
+        out[k] = list(v) if hasattr(v, "__len__") else v
+    return out
 
 
 class Renderer:

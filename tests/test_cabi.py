@@ -37,7 +37,7 @@ def test_struct_layouts_match_the_header():
 def test_identity():
     lib = _ffi.load()
     assert lib.rt_backend_name() == b"hip-gfx950"
-    assert lib.rt_abi_version() == 2
+    assert lib.rt_abi_version() == 3
 
 
 @pytest.mark.parametrize("kw,msg", [

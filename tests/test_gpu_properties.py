@@ -35,6 +35,24 @@ def test_cfg2_accounting(cfg2, book1_flat):
     assert 0.3 < mean.mean() < 0.6
 
 
+@pytest.mark.parametrize("max_depth", [50, 5, 1])
+def test_rays_per_bounce_histogram(renderer, book1_flat, max_depth):
+    """rt_stats.live_per_bounce (RT_FLAG_DIAG_STATS): one camera ray per sample, never more rays at a deeper
+    bounce, nothing at or beyond max_depth, and the histogram sums to rays_traced."""
+    renderer.upload_scene(book1_flat)
+    w, h, spp = 200, 112, 8
+    _, _, st = renderer.render(rt.book1_camera(w, h), rt.make_params(w, h, spp, max_depth=max_depth, flags=rt.RT_FLAG_DIAG_STATS))
+    live = st["live_per_bounce"]
+    assert len(live) == 64 and sum(live) == st["rays_traced"]
+    assert live[0] == st["samples"] == w * h * spp
+    assert all(a >= b for a, b in zip(live, live[1:]))
+    assert all(v == 0 for v in live[min(max_depth, 63):]) if max_depth < 64 else True
+    if max_depth >= 5:
+        assert 0 < live[4] < live[1] < live[0]
+    _, _, st0 = renderer.render(rt.book1_camera(w, h), rt.make_params(w, h, spp, max_depth=max_depth))
+    assert sum(st0["live_per_bounce"]) == 0 and st0["rays_traced"] == st["rays_traced"]       # off without the flag
+
+
 def test_cfg2_is_deterministic(renderer, book1_flat, cfg2):
     w, h, spp, fix, st = cfg2
     renderer.upload_scene(book1_flat)
