@@ -98,12 +98,14 @@ constexpr int kRowPad = 80;         // floats per row of the ray-operand transpo
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// DIAG: also count filter candidates and exact roots (rt_stats.candidates / exact_roots).  Off in
-// the shipped path: the two counters cost 8 spilled registers and 2.5 % of the frame time.
+// DIAG: also count filter candidates, exact roots and rays per bounce index (rt_stats.candidates /
+// exact_roots / live_per_bounce).  Off in the shipped path: the counters cost spilled registers and
+// ~15 % of the frame time.
 template <int MODE, bool DIAG>
 // second launch bound = waves per SIMD the register allocator must leave room for: the bounce loop
-// is latency-bound, and the 4th wave is worth more than the few cold values it spills
-__global__ __launch_bounds__(kBlock, (MODE >= 2) ? 4 : 5) void render_kernel(const KParams P)
+// is latency-bound, and the 4th wave is worth more than the few cold values it spills (the older
+// cross-check modes 2 and 3 keep their 10 KB ray-operand buffer: 3 workgroups per CU fit their LDS)
+__global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void render_kernel(const KParams P)
 {
     __shared__ uint16_t cand[MODE == 1 ? kCandCap : 1][kBlock];     // MODE 1: per-lane candidate lists
     constexpr bool MATRIX = (MODE >= 2);
