@@ -201,6 +201,10 @@ int rt_filter_lifted_device(rt_context *ctx, const double *o, const double *d, c
  * analysed range); out_rho: the radius floor chosen for these 32 spheres. */
 int rt_filter_tube_device(rt_context *ctx, const double *o, const double *d, const rt_sphere *spheres32,
                           float *out_h, float *out_rows, float *out_bound, float *out_rho);
+/* The host half of the same tile, no device needed: the 32 columns exactly as rt_upload_scene lays them
+ * out.  out_words: [64][4] u32 = the B operand of lane l (column l&31, K-slots 8(l>>5)..+7, two bf16 per
+ * word, low half first); out_bound: [32]; out_rho: the radius floor. */
+int rt_tube_tile_host(const rt_sphere *spheres32, uint32_t *out_words, float *out_bound, float *out_rho);
 int rt_philox_device(rt_context *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 #ifdef __cplusplus

@@ -61,6 +61,7 @@ SYMBOLS = [
     ("rt_f64_div_sqrt_device", C.c_int, [_VP, _VP, _VP, C.c_int32, _VP, _VP]),
     ("rt_filter_products_device", C.c_int, [_VP, _VP, _VP, _VP, C.c_int32, _VP, _VP]),
     ("rt_filter_lifted_device", C.c_int, [_VP, _VP, _VP, C.POINTER(rt_sphere), _VP, _VP, _VP]),
+    ("rt_tube_tile_host", C.c_int, [C.POINTER(rt_sphere), _VP, _VP, C.POINTER(C.c_float)]),
     ("rt_filter_tube_device", C.c_int, [_VP, _VP, _VP, C.POINTER(rt_sphere), _VP, _VP, _VP, C.POINTER(C.c_float)]),
 ]
 

@@ -802,6 +802,19 @@ int rt_filter_lifted_device(rt_context *ctx, const double *o, const double *d, c
     return RT_OK;
 }
 
+int rt_tube_tile_host(const rt_sphere *spheres32, uint32_t *out_words, float *out_bound, float *out_rho)
+{
+    if (!spheres32 || !out_words || !out_bound || !out_rho) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    const float rho = tube_radius_floor(spheres32, 32, nullptr);
+    *out_rho = rho;
+    const rt_sphere *col[32];
+    for (int c = 0; c < 32; ++c) col[c] = &spheres32[c];
+    uint4 tile[64];
+    tube_tile(col, rho, tile, out_bound);
+    memcpy(out_words, tile, sizeof(tile));
+    return RT_OK;
+}
+
 int rt_filter_tube_device(rt_context *ctx, const double *o, const double *d, const rt_sphere *spheres32,
                           float *out_h, float *out_rows, float *out_bound, float *out_rho)
 {

@@ -46,6 +46,19 @@ def stats_dict(st):
     return out
 
 
+def tube_tile_host(spheres32):
+    """Host-side half of one tube-filter tile (no GPU): words (64, 4) u32, bound (32,) f32, rho."""
+    lib = _ffi.load()
+    sp = np.ascontiguousarray(spheres32)
+    assert sp.shape == (32,) and sp.dtype.itemsize == C.sizeof(_ffi.rt_sphere)
+    words = np.zeros((64, 4), dtype=np.uint32)
+    bound = np.zeros(32, dtype=np.float32)
+    rho = C.c_float(0.0)
+    _ffi.check(lib.rt_tube_tile_host(sp.ctypes.data_as(C.POINTER(_ffi.rt_sphere)), words.ctypes.data_as(C.c_void_p),
+                                     bound.ctypes.data_as(C.c_void_p), C.byref(rho)), "rt_tube_tile_host")
+    return words, bound, float(rho.value)
+
+
 class Renderer:
     """One rt_context (one GPU)."""
 
