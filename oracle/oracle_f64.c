@@ -284,14 +284,21 @@ typedef struct {
     double *out; trace_ctx *ctxs;
 } job_a;
 
-static void row_a(void *arg, int slot, int worker)
+/* Work unit of the thread pool: kSegCols consecutive pixels of one row (pixels are independent,
+ * main.rs:122-139; whole rows would leave a one-row render on one thread). */
+enum { kSegCols = 64 };
+static int row_segments(const oracle_params *p) { return (p->width + kSegCols - 1) / kSegCols; }
+
+static void row_a(void *arg, int unit, int worker)
 {
     job_a *jb = (job_a *)arg;
     const oracle_params *p = jb->p;
     int step = p->row_step > 0 ? p->row_step : 1;
+    int nseg = row_segments(p), slot = unit / nseg, seg = unit % nseg;
     int j = p->row_begin + slot * step;
+    int i_end = (seg + 1) * kSegCols < p->width ? (seg + 1) * kSegCols : p->width;
     trace_ctx *cx = &jb->ctxs[worker];
-    for (int i = 0; i < p->width; ++i) {
+    for (int i = seg * kSegCols; i < i_end; ++i) {
         vec3 pixel_color = v3(0.0, 0.0, 0.0);
         for (int s = p->sample_begin; s < p->sample_begin + p->spp; ++s)
             pixel_color = add(pixel_color, sample_pixel(jb->cam, cx, p, i, j, s));   /* main.rs:135 */
@@ -326,7 +333,7 @@ int oracle_a_render(const oracle_camera *cam, const oracle_sphere *spheres, int3
     }
     job_a jb = { cam, world, n, p, out_sum, ctxs };
     double t0 = oracle_now_seconds();
-    int used = oracle_parallel_rows(nrows, nthreads, row_a, &jb);
+    int used = oracle_parallel_rows(nrows * row_segments(p), nthreads, row_a, &jb);
     double t1 = oracle_now_seconds();
     if (stats) {
         memset(stats, 0, sizeof(*stats));
@@ -349,14 +356,16 @@ typedef struct {
     uint64_t *out; trace_ctx *ctxs;
 } job_b;
 
-static void row_b(void *arg, int slot, int worker)
+static void row_b(void *arg, int unit, int worker)
 {
     job_b *jb = (job_b *)arg;
     const oracle_params *p = jb->p;
     int step = p->row_step > 0 ? p->row_step : 1;
+    int nseg = row_segments(p), slot = unit / nseg, seg = unit % nseg;
     int j = p->row_begin + slot * step;
+    int i_end = (seg + 1) * kSegCols < p->width ? (seg + 1) * kSegCols : p->width;
     trace_ctx *cx = &jb->ctxs[worker];
-    for (int i = 0; i < p->width; ++i) {
+    for (int i = seg * kSegCols; i < i_end; ++i) {
         uint64_t acc[3] = { 0, 0, 0 };
         for (int s = p->sample_begin; s < p->sample_begin + p->spp; ++s) {
             oracle_rng rng;
@@ -391,7 +400,7 @@ int oracle_b_render(const oracle_camera *cam, const oracle_sphere *spheres, int3
     }
     job_b jb = { cam, world, n, p, out_fix, ctxs };
     double t0 = oracle_now_seconds();
-    int used = oracle_parallel_rows(nrows, nthreads, row_b, &jb);
+    int used = oracle_parallel_rows(nrows * row_segments(p), nthreads, row_b, &jb);
     double t1 = oracle_now_seconds();
     if (out_sum) oracle_b_fix_to_f32(out_fix, (int64_t)nrows * p->width * 3, out_sum);
     if (stats) {
