@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RTIOW_HIP_ABI_VERSION 3
+#define RTIOW_HIP_ABI_VERSION 4
 
 typedef struct rt_context rt_context;
 
@@ -119,10 +119,14 @@ typedef struct {
     float    kernel_ms;          /* render kernel, HIP events on its stream         */
     int32_t  n_spheres;
     int32_t  grid_blocks, block_threads;
-    int32_t  scan_mode;          /* sphere-scan filter that ran: 0 none (RT_FLAG_NO_FILTER), 1..5 */
+    int32_t  scan_mode;          /* sphere-scan filter that ran: 0 none (RT_FLAG_NO_FILTER), 5 tube filter (shipped),
+                                    1 VALU cross-check (RTIOW_SCAN_MODE=1); 2-4 only in RTIOW_CROSSCHECK_MODES builds */
     int32_t  reserved;
     uint64_t live_per_bounce[64]; /* rays traced at bounce index k (0 = camera ray; indices >= 63 share the
                                     last slot); sums to rays_traced (RT_FLAG_DIAG_STATS, else 0) */
+    uint64_t direct_samples;     /* samples added to the frame buffer one by one instead of through their block's
+                                    sums: all of them in a launch of < 37 spp, else only the last samples of blocks
+                                    that a path of more than ~30 bounces held open for too long */
 } rt_stats;
 
 /* ---- lifetime -------------------------------------------------------------- */
@@ -182,18 +186,23 @@ int32_t rt_abi_version(void);
  * two operations whose correct rounding the bit-exact contract leans on). */
 int rt_f64_div_sqrt_device(rt_context *ctx, const double *a, const double *b, int32_t n,
                            double *out_div, double *out_sqrt);
+/* Known-answer hooks of the EARLIER matrix-pipe forms of the filter (scan modes 2-4).
+ * They exist only in a library built with -DRTIOW_CROSSCHECK_MODES (tools/librtiow_hip_xcheck.so, a test
+ * artefact); the product library carries scan modes 0, 1 and 5 and does not export them. */
+#ifdef RTIOW_CROSSCHECK_MODES
 /* The two K = 4 products of the scan filter exactly as the render
  * kernel's matrix-pipe tiles evaluate them: r1, r2: [64][4] ray rows, s: [16][4] sphere
  * columns, out_hb, out_q: [64][16].  bf16x3 != 0 selects the three-piece bf16 form. */
 int rt_filter_products_device(rt_context *ctx, const float *r1, const float *r2, const float *s,
                                int32_t bf16x3, float *out_hb, float *out_q);
-/* One tile of the single-contraction ("lifted") form of the same filter, the shipped scan mode:
+/* One tile of the single-contraction ("lifted") form of the same filter (scan mode 4):
  * o, d: [64][3] f64 rays; spheres16: 16 spheres (one tile of columns, built exactly as
  * rt_upload_scene builds them); out_D: [64][16] the sums whose sign the kernel tests;
  * out_R: [64][11] the per-ray terms (the last entry: 1 if the ray is inside the analysed range);
  * out_C: [16][11] the per-sphere terms. */
 int rt_filter_lifted_device(rt_context *ctx, const double *o, const double *d, const rt_sphere *spheres16,
                             float *out_D, float *out_R, float *out_C);
+#endif /* RTIOW_CROSSCHECK_MODES */
 /* One tile of the tube filter, the shipped scan mode: o, d: [64][3] f64 rays; spheres32: 32 spheres
  * (one tile of columns, built exactly as rt_upload_scene builds them, radius floor included);
  * out_h: [64][32][2] the two per-direction values whose magnitudes the kernel compares with

@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtiow_hip.so")
+# RTIOW_HIP_LIB: load another build of the same ABI instead (the tests use it for the cross-check
+# build tools/librtiow_hip_xcheck.so, which also carries scan modes 2-4 and their known-answer hooks)
+LIB_PATH = os.environ.get("RTIOW_HIP_LIB") or os.path.join(_HERE, "librtiow_hip.so")
 
 
 class rt_sphere(C.Structure):
@@ -33,7 +35,7 @@ class rt_stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays_traced", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("candidates", C.c_uint64), ("exact_roots", C.c_uint64), ("kernel_ms", C.c_float), ("n_spheres", C.c_int32),
                 ("grid_blocks", C.c_int32), ("block_threads", C.c_int32), ("scan_mode", C.c_int32), ("reserved", C.c_int32),
-                ("live_per_bounce", C.c_uint64 * 64)]
+                ("live_per_bounce", C.c_uint64 * 64), ("direct_samples", C.c_uint64)]
 
 
 RT_FLAG_ACCUMULATE = 0x1
@@ -59,10 +61,14 @@ SYMBOLS = [
     ("rt_abi_version", C.c_int32, []),
     ("rt_philox_device", C.c_int, [_VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("rt_f64_div_sqrt_device", C.c_int, [_VP, _VP, _VP, C.c_int32, _VP, _VP]),
-    ("rt_filter_products_device", C.c_int, [_VP, _VP, _VP, _VP, C.c_int32, _VP, _VP]),
-    ("rt_filter_lifted_device", C.c_int, [_VP, _VP, _VP, C.POINTER(rt_sphere), _VP, _VP, _VP]),
     ("rt_tube_tile_host", C.c_int, [C.POINTER(rt_sphere), _VP, _VP, C.POINTER(C.c_float)]),
     ("rt_filter_tube_device", C.c_int, [_VP, _VP, _VP, C.POINTER(rt_sphere), _VP, _VP, _VP, C.POINTER(C.c_float)]),
+]
+
+# declared under RTIOW_CROSSCHECK_MODES in the header: present only in the cross-check build
+XCHECK_SYMBOLS = [
+    ("rt_filter_products_device", C.c_int, [_VP, _VP, _VP, _VP, C.c_int32, _VP, _VP]),
+    ("rt_filter_lifted_device", C.c_int, [_VP, _VP, _VP, C.POINTER(rt_sphere), _VP, _VP, _VP]),
 ]
 
 _lib = None
@@ -94,8 +100,18 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    for name, res, args in XCHECK_SYMBOLS:
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
+
+
+def has_crosscheck_modes():
+    """True when the loaded library is the -DRTIOW_CROSSCHECK_MODES build (scan modes 2-4 and their hooks)."""
+    return hasattr(load(), "rt_filter_lifted_device")
 
 
 def check(rc, what):

@@ -49,21 +49,24 @@ int env_int(const char *name, int dflt)
 struct rt_context {
     int device = 0;
     int cu_count = 0;
-    float *d_filt = nullptr;       // [n][4] f32 filter records
+    float *d_filt = nullptr;       // [n][4] f32 filter records (MODE 1)
     double *d_geo = nullptr;       // [n][4] exact geometry
     double *d_mat = nullptr;       // [n][kMatStride] exact materials
-    float *d_bmat = nullptr;       // [tiles][64] MFMA B operand of the filter
-    float *d_kpt = nullptr;        // [tiles][16] K' per sphere
-    uint4 *d_bmat16 = nullptr;     // [tiles][64] bf16x3 B operand
-    uint4 *d_bmatL = nullptr;      // [tiles][2][64] MODE 4 (lifted form) B operands
     uint4 *d_btube = nullptr;      // [tiles/2 + 1][64] MODE 5 (tube filter) B operands
     float *d_rtube = nullptr;      // [tiles/2 + 1][32] MODE 5 per-sphere bounds
     float tube_rho = 1.0f;         // MODE 5 radius floor
+#ifdef RTIOW_CROSSCHECK_MODES
+    float *d_bmat = nullptr;       // [tiles][64] MFMA B operand of the filter
+    float *d_kpt = nullptr;        // [tiles][16] K' per sphere
+    uint4 *d_bmat16 = nullptr;     // [tiles][64] bf16x3 B operand
     float *d_kpt16 = nullptr;      // [tiles][16] K' for the bf16x3 form
+    uint4 *d_bmatL = nullptr;      // [tiles][2][64] MODE 4 (lifted form) B operands
+#endif
     int n_tiles = 0;
     int n_always = 0;
     int always_idx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int scan_mode = 5;             // filter: 1 VALU + scalar loads, 2 f32 MFMA, 3 bf16x3 MFMA, 4 lifted bf16x3 MFMA, 5 tube bf16x2 MFMA (default)
+    int scan_mode = 5;             // filter: 5 tube bf16x2 MFMA (default, shipped), 1 VALU + scalar loads (cross-check);
+                                   // with -DRTIOW_CROSSCHECK_MODES also 2 f32 MFMA, 3 bf16x3 MFMA, 4 lifted bf16x3 MFMA
     int n_spheres = -1;
     unsigned int *d_queue = nullptr;
     unsigned long long *d_stats = nullptr;
@@ -77,9 +80,7 @@ struct rt_context {
     void *d_stage_sum = nullptr; size_t stage_sum_bytes = 0;
     void *d_stage_rgba = nullptr; size_t stage_rgba_bytes = 0;
     int blocks_per_cu = 0;     // 0 = occupancy query
-    int chunk = 0;             // 0 = default
-    int tail_spp = -1;         // samples per pixel handed out one per item at the end; -1 = automatic
-    int item_block = rt::kItemBlock;
+    int ring_min_spp = rt::kRingMinSpp;   // RTIOW_RING_MIN_SPP (diagnostic): spp per launch from which block sums are kept in LDS
 };
 
 namespace {
@@ -140,6 +141,21 @@ float filter_kprime(const rt_sphere &s, double KU)
     return kp;
 }
 
+uint32_t host_bf16_rne(float x)
+{
+    uint32_t u; memcpy(&u, &x, 4);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+void host_split_bf16x3(float x, uint32_t p[3])
+{
+    auto back = [](uint32_t b) { uint32_t u = b << 16; float f; memcpy(&f, &u, 4); return f; };
+    p[0] = host_bf16_rne(x);
+    const float r1 = x - back(p[0]);
+    p[1] = host_bf16_rne(r1);
+    const float r2 = r1 - back(p[1]);
+    p[2] = host_bf16_rne(r2);
+}
+#ifdef RTIOW_CROSSCHECK_MODES
 // ---- MODE 4 (lifted form, rt_device.hpp): the per-sphere column C_0..C_10 and its 64 K-slots ----
 // `s == nullptr` (padding) or `never` (a sphere on the always-exact list): a column no ray keeps.
 // Every C_k is computed in f64 from the exact centre/radius and rounded once; C_10 = -K' is
@@ -156,20 +172,6 @@ void lifted_column(const rt_sphere *s, bool never, float C[rt::kLiftTerms])
     C[4] = (float)(cx * cx); C[5] = (float)(cy * cy); C[6] = (float)(cz * cz);
     C[7] = (float)(cx * cy); C[8] = (float)(cx * cz); C[9] = (float)(cy * cz);
     C[10] = -kp;
-}
-uint32_t host_bf16_rne(float x)
-{
-    uint32_t u; memcpy(&u, &x, 4);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-void host_split_bf16x3(float x, uint32_t p[3])
-{
-    auto back = [](uint32_t b) { uint32_t u = b << 16; float f; memcpy(&f, &u, 4); return f; };
-    p[0] = host_bf16_rne(x);
-    const float r1 = x - back(p[0]);
-    p[1] = host_bf16_rne(r1);
-    const float r2 = r1 - back(p[1]);
-    p[2] = host_bf16_rne(r2);
 }
 // B-side dwords of the slot layout documented at lifted_a_words()
 void lifted_b_words(const float C[rt::kLiftTerms], uint32_t w[32])
@@ -198,6 +200,8 @@ void lifted_tile(const float C[16][rt::kLiftTerms], uint4 out[128])
             }
     }
 }
+
+#endif // RTIOW_CROSSCHECK_MODES
 
 // ---- MODE 5 (tube filter, rt_device.hpp): per-sphere columns and bounds ----
 // Radius floor rho: the rows of a ray are scaled by rho / (rho + e_ray), which keeps the test sound for
@@ -252,6 +256,29 @@ void tube_tile(const rt_sphere *const s[32], float rho, uint4 out_b[64], float o
     }
 }
 
+// releases every device table of the scene and marks the context as having none
+void free_scene(rt_context *ctx)
+{
+    (void)hipFree(ctx->d_filt); (void)hipFree(ctx->d_geo); (void)hipFree(ctx->d_mat);
+    (void)hipFree(ctx->d_btube); (void)hipFree(ctx->d_rtube);
+    ctx->d_filt = nullptr; ctx->d_geo = ctx->d_mat = nullptr; ctx->d_btube = nullptr; ctx->d_rtube = nullptr;
+#ifdef RTIOW_CROSSCHECK_MODES
+    (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt); (void)hipFree(ctx->d_bmat16); (void)hipFree(ctx->d_kpt16);
+    (void)hipFree(ctx->d_bmatL);
+    ctx->d_bmat = ctx->d_kpt = nullptr; ctx->d_bmat16 = nullptr; ctx->d_kpt16 = nullptr; ctx->d_bmatL = nullptr;
+#endif
+    ctx->n_spheres = -1;
+}
+
+// one table: allocate + copy; on failure the caller frees the whole scene
+template <typename T>
+int upload_table(T **dst, const T *src, size_t count)
+{
+    RT_HIP(hipMalloc((void **)dst, (count ? count : 1) * sizeof(T)));
+    if (count) RT_HIP(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
 template <int MODE, bool DIAG>
 int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, int *grid_out)
 {
@@ -263,7 +290,7 @@ int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, in
     }
     // persistent grid, but never more lanes than there are work items
     long long grid = (long long)ctx->cu_count * per_cu;
-    const long long need = ((long long)kp.total_items + rt::kBlock - 1) / rt::kBlock;
+    const long long need = (long long)((kp.total_items + rt::kBlock - 1) / rt::kBlock);
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
     *grid_out = (int)grid;
@@ -304,12 +331,19 @@ int rt_create(int32_t device_id, rt_context **out)
     ctx->device = device_id;
     ctx->cu_count = prop.multiProcessorCount;
     ctx->blocks_per_cu = env_int("RTIOW_BLOCKS_PER_CU", 0);
-    ctx->chunk = env_int("RTIOW_CHUNK", 0);
-    ctx->tail_spp = env_int("RTIOW_TAIL_SPP", -1);
-    ctx->item_block = env_int("RTIOW_ITEM_BLOCK", rt::kItemBlock);
-    if (ctx->item_block < 64) ctx->item_block = 64;
+    ctx->ring_min_spp = env_int("RTIOW_RING_MIN_SPP", rt::kRingMinSpp);
+    if (ctx->ring_min_spp < rt::kRingMinSpp) ctx->ring_min_spp = rt::kRingMinSpp;     // fewer would overrun the 8 pixel slots
     ctx->scan_mode = env_int("RTIOW_SCAN_MODE", 5);
+#ifdef RTIOW_CROSSCHECK_MODES
     if (ctx->scan_mode < 1 || ctx->scan_mode > 5) ctx->scan_mode = 5;
+#else
+    if (ctx->scan_mode != 1 && ctx->scan_mode != 5) {
+        const int asked = ctx->scan_mode;
+        rt_destroy(ctx);
+        return fail(RT_ERR_INVALID_ARGUMENT, "RTIOW_SCAN_MODE=%d: this build carries scan modes 1 and 5 (modes 2-4 need "
+                    "a -DRTIOW_CROSSCHECK_MODES build)", asked);
+    }
+#endif
     hipError_t e1 = hipMalloc((void **)&ctx->d_queue, 64);
     hipError_t e2 = hipMalloc((void **)&ctx->d_stats, 1024);
     hipError_t e3 = hipEventCreate(&ctx->ev0);
@@ -328,9 +362,7 @@ int rt_destroy(rt_context *ctx)
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
-    (void)hipFree(ctx->d_filt); (void)hipFree(ctx->d_geo); (void)hipFree(ctx->d_mat);
-    (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt); (void)hipFree(ctx->d_bmat16); (void)hipFree(ctx->d_kpt16);
-    (void)hipFree(ctx->d_bmatL); (void)hipFree(ctx->d_btube); (void)hipFree(ctx->d_rtube);
+    free_scene(ctx);
     (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->d_stage_fix); (void)hipFree(ctx->d_stage_sum); (void)hipFree(ctx->d_stage_rgba);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -353,18 +385,14 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
         for (double v : mags)
             if (!(std::fabs(v) < 1e15))
                 return fail(RT_ERR_INVALID_ARGUMENT, "sphere %d: coordinates/radius must be finite and below 1e15", i);
+        // sphere.rs:37 divides by the radius: a zero radius makes every normal inf/NaN in the reference too
+        if (s.radius == 0.0) return fail(RT_ERR_INVALID_ARGUMENT, "sphere %d: radius must not be zero", i);
     }
     RT_HIP(hipSetDevice(ctx->device));
     // the previous scene may still be in use by a launch on any stream
     RT_HIP(hipDeviceSynchronize());
-    (void)hipFree(ctx->d_filt); (void)hipFree(ctx->d_geo); (void)hipFree(ctx->d_mat);
-    (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt); (void)hipFree(ctx->d_bmat16); (void)hipFree(ctx->d_kpt16);
-    (void)hipFree(ctx->d_bmatL); (void)hipFree(ctx->d_btube); (void)hipFree(ctx->d_rtube);
-    ctx->d_filt = nullptr; ctx->d_geo = ctx->d_mat = nullptr; ctx->d_bmat = ctx->d_kpt = nullptr;
-    ctx->d_bmat16 = nullptr; ctx->d_kpt16 = nullptr; ctx->d_bmatL = nullptr; ctx->d_btube = nullptr; ctx->d_rtube = nullptr;
-    ctx->n_spheres = -1;
+    free_scene(ctx);
     const size_t cnt = (size_t)(n > 0 ? n : 1);
-    std::vector<float> filt(cnt * 4, 0.0f);
     std::vector<double> geo(cnt * 4, 0.0), mat(cnt * rt::kMatStride, 0.0);
     for (int i = 0; i < n; ++i) {
         const rt_sphere &s = spheres[i];
@@ -386,14 +414,9 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
             r0 = (1.0 - s.param) / (1.0 + s.param); m[8] = r0 * r0;
             m[2] = 1.0; m[3] = 1.0; m[4] = 1.0;                                  // attenuation (1,1,1), :103
         }
-        // filter record: centre rounded to f32 + K' for the f32 evaluation schemes
-        const float kp = filter_kprime(s, (double)rt::kFilterKU);
-        filt[4 * i + 0] = (float)s.center[0]; filt[4 * i + 1] = (float)s.center[1];
-        filt[4 * i + 2] = (float)s.center[2]; filt[4 * i + 3] = kp;
     }
-    // Matrix-pipe form of the same filter records.  Spheres much larger than the rest of the
-    // scene (the ground) are kept by the filter for nearly every ray: they skip it and are
-    // always tested exactly.  The choice only moves work, never results.
+    // Spheres much larger than the rest of the scene (the ground) are kept by the filter for nearly
+    // every ray: they skip it and are always tested exactly.  The choice only moves work, never results.
     ctx->n_always = 0;
     if (n > 0) {
         std::vector<double> radii(n);
@@ -406,57 +429,13 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
         std::sort(order.begin(), order.end(), [&](int x, int y) { return radii[x] > radii[y]; });
         for (size_t k = 0; k < order.size() && k < 8; ++k) ctx->always_idx[ctx->n_always++] = order[k];
     }
-    // tile count rounded up to even, plus two spare tiles so the pipelined loop never
-    // branches on a table bound (padding columns carry K' = NaN: never kept)
+    // tile count (tiles of 16 columns) rounded up to even, plus two spare tiles so the pipelined loops
+    // never branch on a table bound (padding columns are never kept)
     const int n_tiles = 2 * ((n + 31) / 32);
     ctx->n_tiles = n_tiles;
-    const size_t tcnt = (size_t)n_tiles + 2;
-    std::vector<float> bmat(tcnt * 64, 0.0f), kpt(tcnt * 16, NAN);
-    for (int t = 0; t < n_tiles + 2; ++t)
-        for (int l = 0; l < 64; ++l) {
-            const int i = 16 * t + (l & 15), k = l >> 4;
-            float v = (k == 3) ? 1.0f : 0.0f;                  // padding columns: c = 0
-            if (i < n && k < 3) v = filt[4 * i + k];
-            bmat[(size_t)t * 64 + l] = v;
-        }
-    for (int i = 0; i < n; ++i) kpt[i] = filt[4 * i + 3];      // padding stays NaN: never kept
-    for (int e = 0; e < ctx->n_always; ++e) kpt[ctx->always_idx[e]] = NAN;
-    // bf16x3 form: each S value as three bf16 pieces in the element order the A side pairs
-    // with (rt_device.hpp, a_operand_bf16x3), and K' recomputed with that scheme's larger KU
-    auto bf16_rne = [](float x) -> uint32_t {
-        uint32_t u; memcpy(&u, &x, 4);
-        return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-    };
-    auto bf16_to_f32 = [](uint32_t b) -> float { uint32_t u = b << 16; float x; memcpy(&x, &u, 4); return x; };
-    std::vector<uint4> bmat16(tcnt * 64, make_uint4(0u, 0u, 0u, 0u));
-    std::vector<float> kpt16(tcnt * 16, NAN);
-    for (size_t e = 0; e < bmat.size(); ++e) {
-        const float y = bmat[e];
-        const uint32_t y1 = bf16_rne(y);
-        const float r1 = y - bf16_to_f32(y1);
-        const uint32_t y2 = bf16_rne(r1);
-        const float r2 = r1 - bf16_to_f32(y2);
-        const uint32_t y3 = bf16_rne(r2);
-        bmat16[e] = make_uint4(y1 | (y2 << 16), y1 | (y3 << 16), y2 | (y1 << 16), y3 | (y2 << 16));
-    }
-    for (int i = 0; i < n; ++i) kpt16[i] = filter_kprime(spheres[i], (double)rt::kFilterKU_bf16x3);
-    for (int e = 0; e < ctx->n_always; ++e) kpt16[ctx->always_idx[e]] = NAN;
-    {   // MODE 4 table
-        std::vector<uint4> bmatL(tcnt * 128);
-        std::vector<char> never(n > 0 ? n : 1, 0);
-        for (int e = 0; e < ctx->n_always; ++e) never[ctx->always_idx[e]] = 1;
-        for (size_t t = 0; t < tcnt; ++t) {
-            float C[16][rt::kLiftTerms];
-            for (int c = 0; c < 16; ++c) {
-                const long i = 16 * (long)t + c;
-                lifted_column(i < n ? &spheres[i] : nullptr, i < n && never[i], C[c]);
-            }
-            lifted_tile(C, &bmatL[t * 128]);
-        }
-        RT_HIP(hipMalloc((void **)&ctx->d_bmatL, tcnt * 128 * sizeof(uint4)));
-        RT_HIP(hipMemcpy(ctx->d_bmatL, bmatL.data(), tcnt * 128 * sizeof(uint4), hipMemcpyHostToDevice));
-    }
-    {   // MODE 5 tables
+    int rc = RT_OK;
+    // Only the table of the scan mode this context runs is built (RTIOW_SCAN_MODE, read at rt_create).
+    if (ctx->scan_mode == 5) {      // the tube filter (shipped)
         const size_t ttc = (size_t)n_tiles / 2 + 1;
         std::vector<uint4> btube(ttc * 64);
         std::vector<float> rtube(ttc * 32);
@@ -471,25 +450,72 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
             }
             tube_tile(col, ctx->tube_rho, &btube[t * 64], &rtube[t * 32]);
         }
-        RT_HIP(hipMalloc((void **)&ctx->d_btube, ttc * 64 * sizeof(uint4)));
-        RT_HIP(hipMalloc((void **)&ctx->d_rtube, ttc * 32 * sizeof(float)));
-        RT_HIP(hipMemcpy(ctx->d_btube, btube.data(), ttc * 64 * sizeof(uint4), hipMemcpyHostToDevice));
-        RT_HIP(hipMemcpy(ctx->d_rtube, rtube.data(), ttc * 32 * sizeof(float), hipMemcpyHostToDevice));
+        if (!rc) rc = upload_table(&ctx->d_btube, btube.data(), btube.size());
+        if (!rc) rc = upload_table(&ctx->d_rtube, rtube.data(), rtube.size());
     }
-    RT_HIP(hipMalloc((void **)&ctx->d_bmat16, tcnt * 64 * sizeof(uint4)));
-    RT_HIP(hipMalloc((void **)&ctx->d_kpt16, tcnt * 16 * sizeof(float)));
-    RT_HIP(hipMemcpy(ctx->d_bmat16, bmat16.data(), tcnt * 64 * sizeof(uint4), hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(ctx->d_kpt16, kpt16.data(), tcnt * 16 * sizeof(float), hipMemcpyHostToDevice));
-    RT_HIP(hipMalloc((void **)&ctx->d_bmat, tcnt * 64 * sizeof(float)));
-    RT_HIP(hipMalloc((void **)&ctx->d_kpt, tcnt * 16 * sizeof(float)));
-    RT_HIP(hipMemcpy(ctx->d_bmat, bmat.data(), tcnt * 64 * sizeof(float), hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(ctx->d_kpt, kpt.data(), tcnt * 16 * sizeof(float), hipMemcpyHostToDevice));
-    RT_HIP(hipMalloc((void **)&ctx->d_filt, cnt * 4 * sizeof(float)));
-    RT_HIP(hipMalloc((void **)&ctx->d_geo, cnt * 4 * sizeof(double)));
-    RT_HIP(hipMalloc((void **)&ctx->d_mat, cnt * rt::kMatStride * sizeof(double)));
-    RT_HIP(hipMemcpy(ctx->d_filt, filt.data(), cnt * 4 * sizeof(float), hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(ctx->d_geo, geo.data(), cnt * 4 * sizeof(double), hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(ctx->d_mat, mat.data(), cnt * rt::kMatStride * sizeof(double), hipMemcpyHostToDevice));
+    // filter records of the f32 evaluation schemes (mode 1, and the sources of the mode 2/3 tables):
+    // centre rounded to f32 + K'
+    std::vector<float> filt(cnt * 4, 0.0f);
+    if (ctx->scan_mode >= 1 && ctx->scan_mode <= 3) {
+        for (int i = 0; i < n; ++i) {
+            const rt_sphere &s = spheres[i];
+            filt[4 * i + 0] = (float)s.center[0]; filt[4 * i + 1] = (float)s.center[1];
+            filt[4 * i + 2] = (float)s.center[2]; filt[4 * i + 3] = filter_kprime(s, (double)rt::kFilterKU);
+        }
+        if (ctx->scan_mode == 1 && !rc) rc = upload_table(&ctx->d_filt, filt.data(), filt.size());
+    }
+#ifdef RTIOW_CROSSCHECK_MODES
+    const size_t tcnt = (size_t)n_tiles + 2;
+    if (ctx->scan_mode == 2 || ctx->scan_mode == 3) {
+        std::vector<float> bmat(tcnt * 64, 0.0f), kpt(tcnt * 16, NAN);
+        for (int t = 0; t < n_tiles + 2; ++t)
+            for (int l = 0; l < 64; ++l) {
+                const int i = 16 * t + (l & 15), k = l >> 4;
+                float v = (k == 3) ? 1.0f : 0.0f;                  // padding columns: c = 0
+                if (i < n && k < 3) v = filt[4 * i + k];
+                bmat[(size_t)t * 64 + l] = v;
+            }
+        for (int i = 0; i < n; ++i) kpt[i] = filt[4 * i + 3];      // padding stays NaN: never kept
+        for (int e = 0; e < ctx->n_always; ++e) kpt[ctx->always_idx[e]] = NAN;
+        if (ctx->scan_mode == 2) {
+            if (!rc) rc = upload_table(&ctx->d_bmat, bmat.data(), bmat.size());
+            if (!rc) rc = upload_table(&ctx->d_kpt, kpt.data(), kpt.size());
+        } else {
+            // bf16x3 form: each S value as three bf16 pieces in the element order the A side pairs
+            // with (rt_device.hpp, a_operand_bf16x3), and K' recomputed with that scheme's larger KU
+            std::vector<uint4> bmat16(tcnt * 64, make_uint4(0u, 0u, 0u, 0u));
+            std::vector<float> kpt16(tcnt * 16, NAN);
+            for (size_t e = 0; e < bmat.size(); ++e) {
+                uint32_t y[3]; host_split_bf16x3(bmat[e], y);
+                bmat16[e] = make_uint4(y[0] | (y[1] << 16), y[0] | (y[2] << 16), y[1] | (y[0] << 16), y[2] | (y[1] << 16));
+            }
+            for (int i = 0; i < n; ++i) kpt16[i] = filter_kprime(spheres[i], (double)rt::kFilterKU_bf16x3);
+            for (int e = 0; e < ctx->n_always; ++e) kpt16[ctx->always_idx[e]] = NAN;
+            if (!rc) rc = upload_table(&ctx->d_bmat16, bmat16.data(), bmat16.size());
+            if (!rc) rc = upload_table(&ctx->d_kpt16, kpt16.data(), kpt16.size());
+        }
+    }
+    if (ctx->scan_mode == 4) {
+        std::vector<uint4> bmatL(tcnt * 128);
+        std::vector<char> never(n > 0 ? n : 1, 0);
+        for (int e = 0; e < ctx->n_always; ++e) never[ctx->always_idx[e]] = 1;
+        for (size_t t = 0; t < tcnt; ++t) {
+            float C[16][rt::kLiftTerms];
+            for (int c = 0; c < 16; ++c) {
+                const long i = 16 * (long)t + c;
+                lifted_column(i < n ? &spheres[i] : nullptr, i < n && never[i], C[c]);
+            }
+            lifted_tile(C, &bmatL[t * 128]);
+        }
+        if (!rc) rc = upload_table(&ctx->d_bmatL, bmatL.data(), bmatL.size());
+    }
+#endif
+    if (!rc) rc = upload_table(&ctx->d_geo, geo.data(), geo.size());
+    if (!rc) rc = upload_table(&ctx->d_mat, mat.data(), mat.size());
+    if (rc) {                       // a failed upload leaves NO scene behind (message of the failing call kept)
+        free_scene(ctx);
+        return rc;
+    }
     ctx->n_spheres = n;
     return RT_OK;
 }
@@ -527,30 +553,13 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     hipStream_t stream = (hipStream_t)stream_v;
 
     const long long npix = (long long)rows * p->width;
-    // samples per work item: small enough for a short tail, large enough that the
-    // item count fits 31 bits
-    int chunk = ctx->chunk > 0 ? ctx->chunk : 4;
-    if (chunk > p->spp) chunk = p->spp > 0 ? p->spp : 1;
-    // The last samples of every pixel are handed out ONE per item, after all the chunked items.  The
-    // launch ends when the slowest wave ends; a wave that reserved one of the last blocks of 4-sample
-    // items is ~40 bounces behind one that found the queue empty.  Measured on cfg2 (tools/exit_times.py):
-    // without this phase the average wave idles through the last 8.4 % of the launch, with ~48 single
-    // samples per resident lane 3.1 % (what is left is the longest path of the last samples).
-    // RTIOW_TAIL_SPP overrides.
-    long long tail_spp = ctx->tail_spp;
-    if (tail_spp < 0) {
-        const long long lanes = (long long)ctx->cu_count * 4 * rt::kBlock;      // 4 workgroups per CU stay resident
-        tail_spp = npix > 0 ? (48 * lanes + npix - 1) / npix : 0;
-    }
-    if (tail_spp > p->spp) tail_spp = p->spp;
-    if (chunk <= 1) tail_spp = 0;
-    long long bulk_spp = (long long)p->spp - tail_spp;
-    auto n_items = [&](int ch) { return npix * ((bulk_spp + ch - 1) / ch + tail_spp); };
-    while (n_items(chunk) > 0x7fffffffLL) {
-        if (tail_spp > 0) { tail_spp = 0; bulk_spp = p->spp; } else chunk *= 2;
-    }
-    const long long nchunks = (bulk_spp + chunk - 1) / chunk;
-
+    // Work items are single pixel-samples in pixel-major order (item w = pixel * spp + sample), handed out in
+    // blocks of kItemBlock consecutive items; the work counter counts blocks.
+    const unsigned long long total_items = (unsigned long long)npix * (unsigned long long)p->spp;
+    const unsigned long long n_blocks = (total_items + rt::kItemBlock - 1) / rt::kItemBlock;
+    if (n_blocks > 0x7fffffffULL)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rows*width*spp = %llu pixel-samples in one launch: at most 2^31 blocks of %d "
+                    "(split the samples over several launches with sample_begin and RT_FLAG_ACCUMULATE)", total_items, rt::kItemBlock);
     rt::KParams kp;
     memset(&kp, 0, sizeof(kp));
     static_assert(sizeof(rt::KCamera) == sizeof(rt_camera), "camera layouts must match");
@@ -560,13 +569,24 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.t_min = p->t_min;
     kp.k0 = (uint32_t)p->seed; kp.k1 = (uint32_t)(p->seed >> 32);
     kp.tile_rows = p->tile_rows; kp.shard_index = p->shard_index; kp.shard_count = p->shard_count;
-    kp.rows = rows; kp.n_spheres = ctx->n_spheres; kp.chunk = chunk;
-    kp.item_block = ctx->item_block;
-    kp.npix = (uint32_t)npix; kp.total_items = (uint32_t)(npix * (nchunks + tail_spp));
-    kp.bulk_items = (uint32_t)(npix * nchunks); kp.bulk_spp = (int32_t)bulk_spp;
+    kp.rows = rows; kp.n_spheres = ctx->n_spheres;
+    kp.npix = (uint32_t)npix; kp.total_items = total_items; kp.n_blocks = (uint32_t)n_blocks;
+    kp.inv_spp = p->spp > 0 ? 1.0 / (double)p->spp : 0.0;
+    kp.inv_width = 1.0 / (double)p->width;
+    // udiv_small (rt_kernels.hpp): numerators are < d + 256 (spp, width) or < 65536 (rows / tile_rows), so for
+    // d < 2^15 the product x * d stays below 2^32 and floor(x * M / 2^32) is the exact quotient
+    auto magic_for = [](long long d) -> uint32_t {
+        return (d <= 1 || d >= 32768) ? 0u : (uint32_t)(0x100000000ULL / (unsigned long long)d + 1ULL);
+    };
+    kp.magic_spp = magic_for(p->spp); kp.magic_width = magic_for(p->width); kp.magic_tile = magic_for(p->tile_rows);
+    // a block of kItemBlock consecutive samples touches at most ceil((kItemBlock-1)/spp) + 1 pixels: kRingSlots from 37 spp on
+    kp.use_ring = p->spp >= ctx->ring_min_spp ? 1 : 0;
     kp.filt = ctx->d_filt; kp.geo = ctx->d_geo; kp.mat = ctx->d_mat;
-    kp.bmat = ctx->d_bmat; kp.kpt = ctx->d_kpt; kp.n_tiles = ctx->n_tiles;
+    kp.n_tiles = ctx->n_tiles;
+#ifdef RTIOW_CROSSCHECK_MODES
+    kp.bmat = ctx->d_bmat; kp.kpt = ctx->d_kpt;
     kp.bmat16 = ctx->d_bmat16; kp.kpt16 = ctx->d_kpt16; kp.bmatL = ctx->d_bmatL;
+#endif
     kp.btube = ctx->d_btube; kp.rtube = ctx->d_rtube; kp.tube_rho = ctx->tube_rho;
     kp.n_always = ctx->n_always;
     for (int e = 0; e < 8; ++e) kp.always_idx[e] = ctx->always_idx[e];
@@ -601,12 +621,14 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     case 1: rc = launch_render<0, true>(ctx, kp, stream, &grid); break;
     case 2: rc = launch_render<1, false>(ctx, kp, stream, &grid); break;
     case 3: rc = launch_render<1, true>(ctx, kp, stream, &grid); break;
+#ifdef RTIOW_CROSSCHECK_MODES
     case 4: rc = launch_render<2, false>(ctx, kp, stream, &grid); break;
     case 5: rc = launch_render<2, true>(ctx, kp, stream, &grid); break;
     case 6: rc = launch_render<3, false>(ctx, kp, stream, &grid); break;
     case 7: rc = launch_render<3, true>(ctx, kp, stream, &grid); break;
     case 8: rc = launch_render<4, false>(ctx, kp, stream, &grid); break;
     case 9: rc = launch_render<4, true>(ctx, kp, stream, &grid); break;
+#endif
     case 10: rc = launch_render<5, false>(ctx, kp, stream, &grid); break;
     default: rc = launch_render<5, true>(ctx, kp, stream, &grid); break;
     }
@@ -631,6 +653,7 @@ int rt_last_stats(rt_context *ctx, rt_stats *stats)
     ctx->last.samples = h[1] + ctx->zero_depth_samples;
     ctx->last.candidates = h[2];
     ctx->last.exact_roots = h[3];
+    ctx->last.direct_samples = h[4];
     ctx->last.sphere_tests = h[0] * (unsigned long long)(ctx->last.n_spheres > 0 ? ctx->last.n_spheres : 0);
     ctx->last.kernel_ms = ms;
     *stats = ctx->last;
@@ -751,6 +774,7 @@ int rt_f64_div_sqrt_device(rt_context *ctx, const double *a, const double *b, in
     return RT_OK;
 }
 
+#ifdef RTIOW_CROSSCHECK_MODES
 int rt_filter_products_device(rt_context *ctx, const float *r1, const float *r2, const float *s,
                                int32_t bf16x3, float *out_hb, float *out_q)
 {
@@ -801,6 +825,8 @@ int rt_filter_lifted_device(rt_context *ctx, const double *o, const double *d, c
     RT_HIP(hipStreamSynchronize(ctx->own_stream));
     return RT_OK;
 }
+
+#endif // RTIOW_CROSSCHECK_MODES
 
 int rt_tube_tile_host(const rt_sphere *spheres32, uint32_t *out_words, float *out_bound, float *out_rho)
 {

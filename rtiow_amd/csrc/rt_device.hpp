@@ -86,6 +86,22 @@ __device__ __forceinline__ double u01(uint32_t w) { return (double)(w >> 8) * (1
 // gen_range(-1.0..1.0) / (-1.0..=1.0): 2u - 1 (exact).
 __device__ __forceinline__ double u11(uint32_t w) { return 2.0 * u01(w) - 1.0; }
 
+// The reference's rejection tests on such uniforms (vec3.rs:37-45 `length_squared() < 1.0`, vec3.rs:59-68), exactly.
+// u11(w) = m * 2^-23 with the integer m = (w >> 8) - 2^23 in [-2^23, 2^23); m*m needs 46 bits and a sum of three
+// such squares 48, so every f64 product and sum in `x*x + y*y + z*z` is EXACT and the f64 comparison with 1.0 is
+// the integer comparison sum(m^2) < 2^46.  The retry loops run on the integers and convert the accepted draw once.
+__device__ __forceinline__ long long u11_int(uint32_t w) { return (long long)((int32_t)(w >> 8) - 0x800000); }
+__device__ __forceinline__ bool unit_disk_accepts(uint32_t wx, uint32_t wy)
+{
+    const long long x = u11_int(wx), y = u11_int(wy);
+    return (unsigned long long)(x * x + y * y) < (1ull << 46);
+}
+__device__ __forceinline__ bool unit_sphere_accepts(uint32_t wx, uint32_t wy, uint32_t wz)
+{
+    const long long x = u11_int(wx), y = u11_int(wy), z = u11_int(wz);
+    return (unsigned long long)(x * x + y * y + z * z) < (1ull << 46);
+}
+
 // Contract C5: truncate one radiance channel to the 2^-32 grid.
 __device__ __forceinline__ unsigned long long quantize(double x)
 {

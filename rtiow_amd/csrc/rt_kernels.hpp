@@ -7,10 +7,11 @@
 //     LANE owns one path at a time and never waits for its neighbours -- when
 //     its path ends it immediately starts its next pixel-sample ("path
 //     regeneration"), so the sphere scan always runs with full waves;
-//   * work = items (pixel, chunk of <= `chunk` consecutive samples), then the last
-//     samples of every pixel one per item (a short end of the launch); a wave
-//     reserves a block of items with ONE returning atomic on a device-wide
-//     counter and deals them to its idle lanes (__ballot + popcount + v_mbcnt rank);
+//   * work = single pixel-samples in PIXEL-MAJOR order (item w = pixel * spp + sample); a wave
+//     reserves a block of kItemBlock consecutive items with ONE returning atomic on a device-wide
+//     counter and deals them to its idle lanes (__ballot + popcount + v_mbcnt rank); a block is
+//     at most 8 neighbouring pixels, so its 64-lane wave traces coherent camera rays and the
+//     launch ends on single samples;
 //   * the sphere scan (HittableList::hit, mod.rs:54-70) decides nothing: it is a
 //     conservative FILTER (rt_device.hpp) -- it may send a sphere to the exact
 //     test needlessly, never drop one the reference would hit.  The shipped form
@@ -21,8 +22,10 @@
 //   * spheres the filter keeps are marked in per-ray LDS bitmaps, pooled over the
 //     wave and put through the reference's exact f64 test (sphere.rs:16-34), so every
 //     hit decision and every shading value is the reference's own f64 arithmetic;
-//   * per-lane radiance sums are exact u64 fixed point (contract C5) and are
-//     added to the frame buffer with 64-bit atomics once per item.
+//   * radiance is exact u64 fixed point (contract C5): a finished sample is added to its block's
+//     per-pixel sums in the wave's LDS, and a block goes to the frame buffer ONCE, when its last
+//     sample has finished (one 64-bit atomic per pixel and channel per block: the frame buffer sees
+//     ~3 x 64-byte memory-side requests per 256 samples).
 #pragma once
 #include "rt_device.hpp"
 #include <type_traits>
@@ -43,18 +46,24 @@ struct KParams {
     int32_t tile_rows, shard_index, shard_count;
     int32_t rows;              // compact rows of this shard
     int32_t n_spheres;
-    int32_t chunk;             // samples per work item
-    int32_t item_block;        // work items a wave reserves per atomic (>= 64)
+    int32_t use_ring;          // 1: per-wave LDS block sums (spp >= kRingMinSpp); 0: every sample goes to the frame buffer directly
     uint32_t npix;             // rows * width
-    uint32_t total_items;      // bulk_items + npix * (spp - bulk_spp)
-    uint32_t bulk_items;       // npix * ceil(bulk_spp / chunk): items of `chunk` samples; the rest are single samples
-    int32_t bulk_spp;          // samples per pixel covered by the chunked items
+    uint32_t n_blocks;         // work blocks of kItemBlock consecutive pixel-samples, pixel-major: item w = pixel * spp + sample
+    unsigned long long total_items;   // npix * spp
+    double inv_spp;            // 1.0 / spp (block -> first pixel)
+    double inv_width;          // 1.0 / width (first pixel -> row, column)
+    // per-lane divisions of small numerators by launch constants, as multiply-high (udiv_small below):
+    // floor(2^32 / d) + 1 for d = spp, width, tile_rows (unused where d == 1 or d >= 2^16)
+    uint32_t magic_spp, magic_width, magic_tile;
+    uint32_t pad_magic;
     const float *filt;         // [n][4]  f32 filter record (cx, cy, cz, K')
+#ifdef RTIOW_CROSSCHECK_MODES
     const float *bmat;         // [tiles][64] MFMA B operand: lane l -> S[k=l>>4][sphere 16t+(l&15)], S=(cx,cy,cz,1)
     const float *kpt;          // [tiles][16] K' per sphere (NaN: never kept by the filter)
     const uint4 *bmat16;       // [tiles][64] bf16x3 B operand: 8 bf16 (y1,y2,y1,y3,y2,y1,y3,y2) of S[k][sphere]
     const float *kpt16;        // [tiles][16] K' for the bf16x3 form (larger KU)
     const uint4 *bmatL;        // [tiles][2][64] MODE 4 B operands: the 64 K-slots of the lifted form (rt_device.hpp)
+#endif
     const uint4 *btube;        // [tiles/2 + 1][64] MODE 5 B operands: 32 spheres x 16 K-slots (rt_device.hpp)
     const float *rtube;        // [tiles/2 + 1][32] MODE 5 per-sphere bound max(R, rho); negative: never kept
     float tube_rho;            // MODE 5 radius floor
@@ -65,22 +74,39 @@ struct KParams {
     const double *mat;         // [n][10] exact (1/r, param, albedo rgb, kind, 1/param, r0(1/ir), r0(ir), -)
     unsigned long long *fix;   // [rows][width][3] exact sums
     unsigned int *queue;       // work counter
-    unsigned long long *stats; // [0] rays [1] samples [2] candidates [3] exact roots [8..15] diagnostic builds [16..79] rays per bounce index (DIAG)
+    unsigned long long *stats; // [0] rays [1] samples [2] candidates [3] exact roots [4] samples sent to the frame buffer one by one [8..15] diagnostic builds [16..79] rays per bounce index (DIAG)
 };
 
 constexpr int RT_KIND_LAMBERTIAN = 0, RT_KIND_METAL = 1, RT_KIND_DIALECTRIC = 2;
 constexpr int kBlock = 256;
 constexpr int kCandCap = 24;        // MODE 1: per-lane candidate slots
 constexpr int kScanUnroll = 8;      // MODE 1: spheres per scalar-load batch / overflow check
-constexpr int kItemBlock = 256;     // work items a wave reserves per atomic (>= 64)
+constexpr int kItemBlock = 256;     // pixel-samples a wave reserves per atomic on the work counter
+constexpr int kRingSlots = 8;       // pixels a block may touch when its sums are kept in LDS: ceil(255 / spp) + 1 <= 8
+constexpr int kRingMinSpp = 37;     //   ... which holds from 37 spp per launch on; below that samples go to the frame buffer one by one
+constexpr int kRingDepth = 4;       // blocks of one wave that may be unfinished at the same time (older ones: see `orphan`)
 constexpr int kMatStride = 10;      // doubles per material record
 constexpr int kSegTiles = 36;       // matrix filter: tiles (of 16 spheres) per candidate-bitmap segment
 
 __device__ __forceinline__ D3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
 
+// x / d for a launch constant d >= 1 and a numerator with x < d + 65536 and x < 2^31, without a division (a `/`
+// would have the compiler keep one reciprocal per divisor in a VGPR for the whole bounce loop):
+//   d == 1: x;  d >= 2^15: the quotient is 0 or 1;  else floor(x * M / 2^32), M = floor(2^32/d) + 1,
+//   exact because x * (M d - 2^32) <= x d < 2^32: the numerators here are < d + 256 (spp, width) or < 2^16
+//   (rows / tile_rows), so x d < 2^32 for every d < 2^15.
+__device__ __forceinline__ uint32_t udiv_small(uint32_t x, uint32_t d, uint32_t magic)
+{
+    const uint32_t big = x >= d ? 1u : 0u;
+    const uint32_t q = __umulhi(x, magic);
+    return d == 1u ? x : (d >= 32768u ? big : q);
+}
+
 // MODE 0: every sphere goes through the exact test (validation mode, RT_FLAG_NO_FILTER):
 //         same results by construction of the filter.
 // MODE 1: f32 filter on the VALU with scalar-loaded sphere records + deferred exact tests.
+// MODEs 2-4 are earlier matrix-pipe forms of the filter, kept as cross-checks and compiled only with
+// -DRTIOW_CROSSCHECK_MODES (the product library carries modes 0, 1 and 5):
 // MODE 2: the same filter on the f32 MATRIX pipe: the filter is two K = 4 products,
 //         HB = R1 x S and Q = R2 x S, of per-ray rows R1 = (-g, o.g), R2 = (-2o, |o|^2(1-kappa))
 //         with per-sphere columns S = (c, 1); v_mfma_f32_16x16x4_f32 evaluates them for
@@ -124,16 +150,25 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
     __shared__ unsigned int s_pool[MATRIX ? kBlock / 64 : 1][MATRIX ? 128 : 1];
     __shared__ unsigned long long s_best[MATRIX ? kBlock : 1];
     __shared__ unsigned int s_bidx[MATRIX ? kBlock : 1];
-    // the item's running sums (exact u64 fixed point) live in LDS, not in 6 VGPRs: they are touched
-    // once per finished sample, and registers are what the 4th wave per SIMD is paid with
-    __shared__ unsigned long long s_acc[3][kBlock];
+    // Per wave, the exact sums (u64 fixed point) of up to kRingDepth unfinished blocks, [pixel slot][channel]; a block is
+    // written to the frame buffer once, by whichever pass finishes its last sample.  s_rcnt: 0 = free, else
+    // 1 + (kItemBlock - items of the block) + samples finished, so every block completes at kItemBlock + 1;
+    // s_rseq: sequence number of the block that owns the entry; s_rpix: its first pixel (compact index).
+    __shared__ unsigned long long s_ring[kBlock / 64][kRingDepth][kRingSlots * 3];
+    __shared__ unsigned int s_rcnt[kBlock / 64][kRingDepth];
+    __shared__ unsigned int s_rseq[kBlock / 64][kRingDepth];
+    __shared__ unsigned int s_rpix[kBlock / 64][kRingDepth];
     __shared__ unsigned int s_live[DIAG ? kBlock / 64 : 1][DIAG ? 64 : 1];    // DIAG: rays per bounce index, per wave
     // so does the path throughput (contract C3): read and written once per bounce
     __shared__ double s_thr[3][kBlock];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    s_acc[0][tid] = 0ull; s_acc[1][tid] = 0ull; s_acc[2][tid] = 0ull;    // own slots only: no barrier needed
+    {   // this wave's block sums and their bookkeeping (own wave only: no barrier needed)
+        unsigned long long *z = &s_ring[tid >> 6][0][0];
+        for (int k = lane; k < kRingDepth * kRingSlots * 3; k += 64) z[k] = 0ull;
+        if (lane < kRingDepth) { s_rcnt[tid >> 6][lane] = 0u; s_rseq[tid >> 6][lane] = 0xFFFFFFFFu; s_rpix[tid >> 6][lane] = 0u; }
+    }
     if (DIAG) s_live[tid >> 6][tid & 63] = 0u;                          // this wave's row only
     // number of set bits of a wave mask below this lane (v_mbcnt: no per-lane 64-bit mask to keep)
     auto rank_below = [](unsigned long long m) -> uint32_t {
@@ -152,16 +187,35 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
     const double wm1 = (double)(P.width - 1);
     const double hm1 = (double)(P.height - 1);
 
-    bool has_item = false, dead = false, alive = false;
+    bool dead = false, alive = false;
     uint32_t pix_local = 0, pix_global = 0;
-    int s = 0, s_end = 0;
+    int s = 0;
     uint32_t px_ij = 0;                            // pixel column | row << 16 (rt_params: both < 65536)
+    uint32_t my_blk = 0;                           // sequence number (within this wave) of the block of this lane's sample << 4 | its pixel slot
     D3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     int depth = 0;
     uint32_t ev = 0;
-    uint32_t n_rays = 0, n_samples = 0;            // wave totals (uniform)
+    uint32_t n_rays = 0, n_samples = 0, n_direct = 0;   // wave totals (uniform)
     unsigned long long tot_cand = 0, tot_roots = 0;     // wave totals (uniform)
-    uint32_t wave_next = 0, wave_end = 0;          // this wave's reserved block of work items (uniform)
+    // this wave's current block of work items (all wave-uniform): items [blk_next, blk_end) of it are still to be dealt;
+    // its first item is sample blk_s0 of compact pixel blk_pix0 = row blk_rr0, column blk_i0 of the shard
+    uint32_t blk_next = 0, blk_end = 0, blk_seq = 0xFFFFFFFFu, blk_pix0 = 0, blk_s0 = 0, blk_rr0 = 0, blk_i0 = 0;
+    bool queue_empty = false;
+    unsigned long long *ring_w = &s_ring[tid >> 6][0][0];
+    unsigned int *rcnt_w = &s_rcnt[tid >> 6][0], *rseq_w = &s_rseq[tid >> 6][0], *rpix_w = &s_rpix[tid >> 6][0];
+    // one block's sums -> frame buffer (wave-uniform call; `e` uniform): lane l < 24 holds (pixel slot l/3, channel l%3),
+    // which are 24 consecutive u64 of the frame buffer; zero sums (unused slots, black pixels) are not sent
+    auto flush_ring = [&](uint32_t e) {
+        if (lane < kRingSlots * 3) {
+            const unsigned long long v = ring_w[e * (kRingSlots * 3) + lane];
+            if (v != 0ull) {
+                atomicAdd(P.fix + (size_t)rpix_w[e] * 3u + (size_t)lane, v);
+                ring_w[e * (kRingSlots * 3) + lane] = 0ull;
+            }
+        }
+        if (lane == 0) rcnt_w[e] = 0u;
+        __builtin_amdgcn_wave_barrier();
+    };
 
 #ifdef RT_PHASE_STAMPS
     // Diagnostic build only (never the shipped library): wave-time spent per phase, summed
@@ -186,66 +240,98 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
 #endif
     for (;;) {
         RT_COUNT(0);
-        // ---- (a) idle lanes take work items ------------------------------------
+        // ---- (a) idle lanes take the next pixel-samples of the wave's block ------------------
         // A wave reserves kItemBlock consecutive items with ONE returning atomic on the
         // device-wide counter and deals them to its lanes (ballot -> popcount -> prefix rank)
         // until the block is used up: one word sustains only ~88 dequeues/us chip-wide
         // (MI355X_MICROARCH.md, row "dequeue"), and a fetch per wave per bounce hit that wall.
-        {
-            const bool want = !has_item && !dead;
+        bool fresh = false;                                         // this lane starts a sample in this pass
+        for (;;) {
+            const bool want = !alive && !dead && !fresh;
             const unsigned long long m = __ballot(want);
-            if (m != 0ull) {
-                const uint32_t cnt = (uint32_t)__popcll(m);
-                const uint32_t avail = wave_end - wave_next;
-                uint32_t newbase = 0;
-                if (cnt > avail) {                                  // wave-uniform
+            if (m == 0ull) break;
+            if (blk_next == blk_end) {                              // (wave-uniform) the block is used up: reserve the next one
+                uint32_t nb = 0xFFFFFFFFu;
+                if (!queue_empty) {
                     const int leader = (int)__builtin_ctzll(m);
-                    if (lane == leader) newbase = atomicAdd(P.queue, (unsigned)P.item_block);
-                    newbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(newbase, leader));
+                    if (lane == leader) nb = atomicAdd(P.queue, 1u);
+                    nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(nb, leader));
                 }
-                if (want) {
-                    const uint32_t r = rank_below(m);
-                    const uint32_t w = (r < avail) ? wave_next + r : newbase + (r - avail);
-                    if (w < P.total_items) {
-                        // items [0, bulk_items): (chunk c, pixel), chunk-major; then one sample per item
-                        const bool single = w >= P.bulk_items;
-                        const uint32_t wr = single ? w - P.bulk_items : w;
-                        const uint32_t c = wr / P.npix;
-                        pix_local = wr - c * P.npix;
-                        const uint32_t rr = pix_local / (uint32_t)P.width;
-                        const uint32_t i = pix_local - rr * (uint32_t)P.width;
-                        const uint32_t lt = rr / (uint32_t)P.tile_rows;            // local tile
-                        const uint32_t j = (lt * (uint32_t)P.shard_count + (uint32_t)P.shard_index) * (uint32_t)P.tile_rows
-                                           + (rr - lt * (uint32_t)P.tile_rows);
-                        pix_global = j * (uint32_t)P.width + i;
-                        px_ij = i | (j << 16);
-                        s = P.sample_begin + (single ? P.bulk_spp + (int)c : (int)c * P.chunk);
-                        s_end = single ? s + 1 : min(s + P.chunk, P.sample_begin + P.bulk_spp);
-                        has_item = true;
-                    } else {
-                        dead = true;
-                    }
+                if (nb >= P.n_blocks) {                             // no work left anywhere: these lanes are done
+                    queue_empty = true;
+                    if (want) dead = true;
+                    break;
                 }
-                if (cnt > avail) { wave_next = newbase + (cnt - avail); wave_end = newbase + (uint32_t)P.item_block; }
-                else wave_next += cnt;
+                // first item of the block -> (pixel, sample): W0 / spp in f64 (W0 < 2^39: exact), one correction step
+                const unsigned long long W0 = (unsigned long long)nb * (unsigned long long)kItemBlock;
+                const unsigned long long left = P.total_items - W0;
+                const uint32_t n_items = left < (unsigned long long)kItemBlock ? (uint32_t)left : (uint32_t)kItemBlock;
+                uint32_t p0 = (uint32_t)((double)W0 * P.inv_spp);
+                long long rem = (long long)(W0 - (unsigned long long)p0 * (unsigned long long)(uint32_t)P.spp);
+                if (rem < 0) { p0 -= 1u; rem += (long long)P.spp; }
+                else if (rem >= (long long)P.spp) { p0 += 1u; rem -= (long long)P.spp; }
+                blk_pix0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);
+                blk_s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rem);
+                uint32_t rr0 = (uint32_t)((double)blk_pix0 * P.inv_width);     // pixel / width the same way
+                int i0 = (int)(blk_pix0 - rr0 * (uint32_t)P.width);
+                if (i0 < 0) { rr0 -= 1u; i0 += P.width; } else if (i0 >= P.width) { rr0 += 1u; i0 -= P.width; }
+                blk_rr0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rr0);                  // (keeps them in SGPRs)
+                blk_i0 = (uint32_t)__builtin_amdgcn_readfirstlane(i0);
+                blk_next = 0u; blk_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_items);
+                blk_seq += 1u;
+                if (P.use_ring) {
+                    // the ring entry may still belong to a block kRingDepth reservations ago that has samples in flight
+                    // (a path of > ~30 bounces): what it has collected goes out now, and its remaining samples will
+                    // find the entry re-assigned and go to the frame buffer directly ("orphans")
+                    const uint32_t e = blk_seq & (uint32_t)(kRingDepth - 1);
+                    if (__builtin_amdgcn_readfirstlane((int)rcnt_w[e]) != 0) flush_ring(e);
+                    if (lane == 0) { rcnt_w[e] = 1u + ((uint32_t)kItemBlock - n_items); rseq_w[e] = blk_seq & 0x0FFFFFFFu; rpix_w[e] = blk_pix0; }
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
+            const uint32_t avail = blk_end - blk_next;
+            const uint32_t r = rank_below(m);
+            if (want && r < avail) {
+                // item blk_next + r of the block: sample blk_s0 + that of pixel blk_pix0, carried over into the next pixels
+                const uint32_t s_rel = blk_s0 + blk_next + r;
+                const uint32_t dq = udiv_small(s_rel, (uint32_t)P.spp, P.magic_spp);   // pixel slot within the block (< kRingSlots when use_ring)
+                const uint32_t col = blk_i0 + dq;
+                const uint32_t rq = udiv_small(col, (uint32_t)P.width, P.magic_width);
+                const uint32_t i = col - rq * (uint32_t)P.width;
+                const uint32_t rr = blk_rr0 + rq;
+                const uint32_t lt = udiv_small(rr, (uint32_t)P.tile_rows, P.magic_tile);   // local tile
+                const uint32_t j = (lt * (uint32_t)P.shard_count + (uint32_t)P.shard_index) * (uint32_t)P.tile_rows
+                                   + (rr - lt * (uint32_t)P.tile_rows);
+                pix_local = blk_pix0 + dq;
+                pix_global = j * (uint32_t)P.width + i;
+                px_ij = i | (j << 16);
+                s = P.sample_begin + (int)(s_rel - dq * (uint32_t)P.spp);
+                my_blk = (blk_seq << 4) | dq;
+                fresh = true;
+            }
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            blk_next += cnt < avail ? cnt : avail;
         }
 
         RT_STAMP(0);
-        // ---- (b) start the next sample: main.rs:131-134 + camera.rs:47-54 ----
-        if (has_item && !alive) {
+        // ---- (b) start the sample: main.rs:131-134 + camera.rs:47-54 ----
+        if (fresh) {
             RT_COUNT(1);
             U4 w = philox4x32_10(pix_global, (uint32_t)s, 0u, 0u, P.k0, P.k1);
             ev = 1u;
             const double u = ((double)(px_ij & 0xFFFFu) + u01(w.x)) / wm1;   // main.rs:131
             const double v = ((double)(px_ij >> 16) + u01(w.y)) / hm1;       // main.rs:132
-            double lx = u11(w.z), ly = u11(w.w);
-            while (!(length_squared(mk(lx, ly, 0.0)) < 1.0)) {      // vec3.rs:59-68
+            // vec3.rs:59-68: redraw until x*x + y*y < 1.  x = u11(w) = m * 2^-23 with the integer m = (w >> 8) - 2^23, and
+            // the f64 sum of squares of such values is EXACT (47 bits), so the reference's f64 comparison is the integer
+            // comparison m_x^2 + m_y^2 < 2^46: the loop runs on integers, the accepted pair is converted once.
+            uint32_t wx = w.z, wy = w.w;
+            while (!unit_disk_accepts(wx, wy)) {
                 RT_COUNT(2);
                 w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
                 ev++;
-                lx = u11(w.x); ly = u11(w.y);
+                wx = w.x; wy = w.y;
             }
+            const double lx = u11(wx), ly = u11(wy);
             const D3 cam_origin = ld3(P.cam.origin);
             const D3 rd = mk(lx, ly, 0.0) * P.cam.lens_radius;
             const D3 offset = ld3(P.cam.u) * rd.x + ld3(P.cam.v) * rd.y;
@@ -313,6 +399,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
             const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
             unsigned int *bits_w = &s_bits[wave][0][0];             // [word][ray]
             unsigned int *sum_w = &s_sum[wave * 64];
+#ifdef RTIOW_CROSSCHECK_MODES
             // Results of half a tile: Dv[g][i] belongs to ray 16(2h+g) + 4 quad + i and sphere
             // 16 t + col; it is kept iff Dv >= kp.  Hits are rare, so the eight values are first
             // folded into one maximum and one wave-level branch.
@@ -378,6 +465,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                     }
                 }
             };
+#endif // RTIOW_CROSSCHECK_MODES
             // ---- candidates -> exact tests, pooled over the wave -------------------------
             // A ray has 1.1 candidates on average but the longest list in a wave has 5-6, and the
             // exact test is ~80 f64 instructions: testing list entry k of every lane together would
@@ -416,6 +504,8 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 const int src = r << 2;
                 const D3 ro = mk(from_lane_f64(src, o.x), from_lane_f64(src, o.y), from_lane_f64(src, o.z));
                 const D3 rd = mk(from_lane_f64(src, d.x), from_lane_f64(src, d.y), from_lane_f64(src, d.z));
+                bool has_root = false;
+                unsigned long long key = 0ull;
                 if (act) {
                     if (DIAG) n_cand++;
                     // sphere.rs:16-34, exactly as exact_test() computes it
@@ -432,13 +522,23 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                         if (root < t_min) root = (-half_b + sqrtd) / ra;
                         if (!(root < t_min)) {
                             // (a NaN root maps above +inf and never wins, as in exact_test(); -0 -> +0)
-                            const unsigned long long key = f64_key(root + 0.0);
-                            const unsigned long long old = atomicMin(&best_w[r], key);
-                            if (old > key) bidx_w[r] = 0u;              // a new minimum: forget the old index
-                            if (best_w[r] == key) atomicMax(&bidx_w[r], (unsigned)idx + 1u);
+                            key = f64_key(root + 0.0);
+                            has_root = true;
                         }
                     }
                 }
+                // Three phases, each by all lanes before the next begins (LDS operations of one wave execute in program
+                // order; the wave barriers keep the compiler from moving one phase's LDS operations into another's):
+                // (1) every root lowers its ray's minimum; (2) a lane that lowered it forgets the sphere recorded for the
+                // old minimum; (3) the roots EQUAL to the final minimum record the largest sphere index among them --
+                // the order-independent form of mod.rs:61-67 (smallest root, ties -> the later sphere of the list).
+                unsigned long long old = 0ull;
+                if (has_root) old = atomicMin(&best_w[r], key);
+                __builtin_amdgcn_wave_barrier();
+                if (has_root && old > key) bidx_w[r] = 0u;
+                __builtin_amdgcn_wave_barrier();
+                if (has_root && best_w[r] == key) atomicMax(&bidx_w[r], (unsigned)idx + 1u);
+                __builtin_amdgcn_wave_barrier();
                 pool_done = min(pool_done + 64u, pool_n);
             };
             // owners push the candidates of segment seg0 (ascending sphere order); rounds run as the ring fills
@@ -609,7 +709,9 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                     enumerate(seg0);
                 }
                 finish_pool();
-            } else if constexpr (LIFTED) {
+            }
+#ifdef RTIOW_CROSSCHECK_MODES
+            else if constexpr (LIFTED) {
                 const LiftedRay L = alive ? make_lifted(o, d) : no_lifted_ray();
                 bf16x8 A[4][2];
                 {
@@ -750,6 +852,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
             }
             finish_pool();
             }
+#endif // RTIOW_CROSSCHECK_MODES
         }
         RT_STAMP(2);
         if (alive && !MATRIX) {
@@ -803,6 +906,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
         RT_STAMP(3);
         // ---- (e) shade: main.rs:44-56 + materials.rs ----------------------------
         bool finished = false;                                          // this lane's sample ended in this pass
+        D3 radiance = mk(0.0, 0.0, 0.0);
         if (alive) {
             bool done = false;
             D3 L = mk(0.0, 0.0, 0.0);
@@ -833,13 +937,14 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 w_first = w.x;
                 if (kind != RT_KIND_DIALECTRIC) {
                     ev++;
-                    sp = mk(u11(w.x), u11(w.y), u11(w.z));
-                    while (!(length_squared(sp) < 1.0)) {                        // vec3.rs:37-45
+                    // vec3.rs:37-45: redraw until |p|^2 < 1 -- on the integers behind the three uniforms, where the
+                    // reference's f64 comparison is exact (see unit_sphere_accepts); converted once, after the loop
+                    while (!unit_sphere_accepts(w.x, w.y, w.z)) {
                         RT_COUNT(6);
                         w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
                         ev++;
-                        sp = mk(u11(w.x), u11(w.y), u11(w.z));
                     }
+                    sp = mk(u11(w.x), u11(w.y), u11(w.z));
                 } else {
                     const double2 mD = *reinterpret_cast<const double2 *>(mrec + 6);  // 1/ir, r0(1/ir)
                     const double2 mE = *reinterpret_cast<const double2 *>(mrec + 8);  // r0(ir), -
@@ -897,25 +1002,42 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 if (depth <= 0) done = true;                                    // main.rs:40-42: L = 0
             }
             if (done) {
-                const unsigned long long a0 = s_acc[0][tid] + quantize(L.x);
-                const unsigned long long a1 = s_acc[1][tid] + quantize(L.y);
-                const unsigned long long a2 = s_acc[2][tid] + quantize(L.z);
                 alive = false;
                 finished = true;
-                s++;
-                if (s >= s_end) {
+                radiance = L;
+            }
+        }
+        // ---- (f) finished samples -> their block's sums (LDS) or, without a ring entry, the frame buffer ----
+        {
+            bool completes = false, direct = false;
+            const uint32_t e = (my_blk >> 4) & (uint32_t)(kRingDepth - 1);
+            if (finished) {
+                const unsigned long long q0 = quantize(radiance.x), q1 = quantize(radiance.y), q2 = quantize(radiance.z);
+                direct = !(P.use_ring && rseq_w[e] == (my_blk >> 4));
+                if (!direct) {
+                    unsigned long long *acc = ring_w + e * (kRingSlots * 3) + (my_blk & 15u) * 3u;
+                    atomicAdd(acc + 0, q0); atomicAdd(acc + 1, q1); atomicAdd(acc + 2, q2);
+                    completes = atomicAdd(&rcnt_w[e], 1u) == (uint32_t)kItemBlock;      // this was the block's last sample
+                } else {                                            // spp < kRingMinSpp, or an orphan of a long-gone block
                     unsigned long long *px = P.fix + (size_t)pix_local * 3u;
-                    atomicAdd(px + 0, a0); atomicAdd(px + 1, a1); atomicAdd(px + 2, a2);
-                    s_acc[0][tid] = 0ull; s_acc[1][tid] = 0ull; s_acc[2][tid] = 0ull;
-                    has_item = false;
-                } else {
-                    s_acc[0][tid] = a0; s_acc[1][tid] = a1; s_acc[2][tid] = a2;
+                    atomicAdd(px + 0, q0); atomicAdd(px + 1, q1); atomicAdd(px + 2, q2);
                 }
+            }
+            n_direct += (uint32_t)__popcll(__ballot(direct));
+            unsigned long long cm = __ballot(completes);
+            while (cm != 0ull) {                                    // (rare: once per block)
+                const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)__builtin_ctzll(cm));
+                flush_ring(ce);
+                cm &= ~__ballot(completes && e == ce);
             }
         }
         n_samples += (uint32_t)__popcll(__ballot(finished));
         RT_STAMP(4);
     }
+    // every block of this wave has finished its last sample and has been written out; a ring entry that
+    // still holds something here would be a bookkeeping error -- its sums go out rather than get lost
+    for (uint32_t e = 0; e < (uint32_t)kRingDepth; ++e)
+        if (__builtin_amdgcn_readfirstlane((int)rcnt_w[e]) != 0) flush_ring(e);
 
         // (end of the bounce loop body is stamped at the top of the next iteration as phase 4)
     // wave totals -> device counters
@@ -940,6 +1062,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
         if (lane == 0) {
             atomicAdd(P.stats + 0, (unsigned long long)n_rays);
             atomicAdd(P.stats + 1, (unsigned long long)n_samples);
+            if (n_direct) atomicAdd(P.stats + 4, (unsigned long long)n_direct);
             atomicAdd(P.stats + 2, nc);
             atomicAdd(P.stats + 3, nr);
         }
@@ -1000,6 +1123,7 @@ __global__ void philox_kat_kernel(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
     out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
 }
 
+#ifdef RTIOW_CROSSCHECK_MODES
 // Known-answer hook for the matrix forms of the filter: one wave, 64 ray rows x 16 sphere
 // columns; returns HB and Q exactly as the render kernel's tiles compute them
 // (bf16x3 != 0: v_mfma_f32_16x16x32_bf16 on three-piece operands; else v_mfma_f32_16x16x4_f32).
@@ -1054,6 +1178,8 @@ __global__ __launch_bounds__(64) void lifted_products_kernel(const double *o, co
         for (int i = 0; i < 4; ++i) D_out[(16 * G + 4 * quad + i) * 16 + col] = acc[i];
     }
 }
+
+#endif // RTIOW_CROSSCHECK_MODES
 
 // One tile of the MODE 5 (tube) filter exactly as the render kernel evaluates it: 64 rays against
 // the 32 columns of `tile`.  h_out[ray][column][k] = lambda u_k.(c - o) as the matrix pipe returns it;

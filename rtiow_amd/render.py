@@ -152,7 +152,10 @@ class Renderer:
         return q, r
 
     def filter_products(self, r1, r2, s, bf16x3=True):
-        """Matrix-pipe filter products HB = R1 x S^T, Q = R2 x S^T (known-answer test hook)."""
+        """Matrix-pipe filter products HB = R1 x S^T, Q = R2 x S^T of scan modes 2/3 (known-answer test
+        hook; cross-check build only)."""
+        if not _ffi.has_crosscheck_modes():
+            raise _ffi.RtiowHipError("rt_filter_products_device needs the -DRTIOW_CROSSCHECK_MODES build (RTIOW_HIP_LIB)")
         r1 = np.ascontiguousarray(r1, dtype=np.float32).reshape(64, 4)
         r2 = np.ascontiguousarray(r2, dtype=np.float32).reshape(64, 4)
         s = np.ascontiguousarray(s, dtype=np.float32).reshape(16, 4)
@@ -165,10 +168,12 @@ class Renderer:
         return hb, q
 
     def filter_lifted(self, o, d, spheres16):
-        """One tile of the single-contraction filter (the shipped scan mode), as the kernel evaluates it.
+        """One tile of the single-contraction filter (scan mode 4; cross-check build only), as the kernel evaluates it.
 
         o, d: (64, 3) f64 rays; spheres16: structured array (SPHERE_DTYPE) of 16 spheres.
         Returns D (64, 16) f32, R (64, 11) f32 per-ray terms, C (16, 11) f32 per-sphere terms."""
+        if not _ffi.has_crosscheck_modes():
+            raise _ffi.RtiowHipError("rt_filter_lifted_device needs the -DRTIOW_CROSSCHECK_MODES build (RTIOW_HIP_LIB)")
         o = np.ascontiguousarray(o, dtype=np.float64).reshape(64, 3)
         d = np.ascontiguousarray(d, dtype=np.float64).reshape(64, 3)
         sp = np.ascontiguousarray(spheres16)

@@ -12,10 +12,14 @@ import rtiow_amd as rt
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
+def header_functions(crosscheck=False):
     src = open(os.path.join(ROOT, "include", "rtiow_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", src)))
+    # declarations under RTIOW_CROSSCHECK_MODES belong to the cross-check build only
+    xsrc = "".join(re.findall(r"#ifdef RTIOW_CROSSCHECK_MODES(.*?)#endif", src, flags=re.S))
+    src = re.sub(r"#ifdef RTIOW_CROSSCHECK_MODES.*?#endif", "", src, flags=re.S)
+    names = lambda t: sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", t)))
+    return (names(xsrc) if crosscheck else names(src))
 
 
 def test_library_exports_every_declared_symbol():
@@ -25,6 +29,20 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/rtiow_hip.h but not exported"
     assert sorted(n for n, _, _ in _ffi.SYMBOLS) == names      # the binding covers the whole header
+    xnames = header_functions(crosscheck=True)
+    assert sorted(n for n, _, _ in _ffi.XCHECK_SYMBOLS) == xnames and len(xnames) == 2
+    if "RTIOW_HIP_LIB" not in os.environ:                      # the product library does not carry modes 2-4
+        assert not any(hasattr(lib, n) for n in xnames) and not _ffi.has_crosscheck_modes()
+
+
+def test_crosscheck_library_exports_the_whole_header():
+    """tools/librtiow_hip_xcheck.so (built by __graft_entry__.build()) = the product ABI + the two hooks."""
+    path = os.path.join(ROOT, "tools", "librtiow_hip_xcheck.so")
+    if not os.path.exists(path):
+        pytest.skip("cross-check library not built")
+    lib = C.CDLL(path)
+    for n in header_functions() + header_functions(crosscheck=True):
+        assert hasattr(lib, n), n
 
 
 def test_struct_layouts_match_the_header():
@@ -37,7 +55,7 @@ def test_struct_layouts_match_the_header():
 def test_identity():
     lib = _ffi.load()
     assert lib.rt_backend_name() == b"hip-gfx950"
-    assert lib.rt_abi_version() == 3
+    assert lib.rt_abi_version() == 4
 
 
 @pytest.mark.parametrize("kw,msg", [

@@ -214,3 +214,72 @@ def test_random_scenes_and_cameras_bit_exact(renderer, oracle_mod, case):
     fb, sb, stb = oracle_mod.render_b(oracle_mod.camera_from_host(cam), flat, oracle_mod.make_params(w, h, spp, seed=seed))
     assert np.array_equal(fix, fb), case
     assert st["rays_traced"] == stb["rays_traced"]
+
+
+@pytest.mark.parametrize("w,h,spp", [(64, 36, 37), (48, 27, 100), (33, 19, 255), (31, 17, 256), (29, 16, 257), (23, 13, 600)])
+def test_block_sums_in_lds_bit_exact(renderer, oracle_mod, book1_flat, w, h, spp):
+    """From 37 spp per launch on a wave keeps the sums of its work blocks (256 consecutive pixel-samples,
+    pixel-major: up to 8 pixels) in LDS and writes a block to the frame buffer once.  Sizes chosen so that
+    blocks start and end in the middle of pixels and rows (spp not a divisor of 256, odd widths, a last
+    block of fewer than 256 items)."""
+    (sm, fix, st), (fb, sb, stb), _ = both(renderer, oracle_mod, book1_flat, w, h, spp)
+    assert np.array_equal(fix, fb) and np.array_equal(sm, sb)
+    assert st["rays_traced"] == stb["rays_traced"] and st["samples"] == w * h * spp
+    assert st["direct_samples"] < st["samples"] // 100           # (orphans of 50-bounce paths only)
+
+
+def test_small_spp_goes_to_the_frame_buffer_directly(renderer, oracle_mod, book1_flat):
+    (sm, fix, st), (fb, _, _), _ = both(renderer, oracle_mod, book1_flat, 80, 45, 36)
+    assert np.array_equal(fix, fb) and st["direct_samples"] == st["samples"] == 80 * 45 * 36
+
+
+def test_hall_of_mirrors_runs_paths_to_the_depth_limit(renderer, oracle_mod):
+    """The camera between two large fuzz-0 metal spheres, a glass and a diffuse sphere around: 6.4 rays per
+    sample on average and paths that run out of depth (main.rs:40-42) -- blocks of work are held open by
+    single long paths for many passes.  (Blocks held open long enough to lose their LDS entry -- "orphans" --
+    need a short AVERAGE path beside the long ones: test_gpu_properties.py checks them on configs[1].)"""
+    flat = hand_scene([
+        rt.Sphere(rt.Point3(0, -1000, 0), 1000, rt.Metal(rt.Color(0.9, 0.9, 0.9), 0.0)),
+        rt.Sphere(rt.Point3(0, 1002.5, 0), 1000, rt.Metal(rt.Color(0.95, 0.95, 0.95), 0.0)),
+        rt.Sphere(rt.Point3(0, 1, 0), 1.0, rt.Dialectric(1.5)),
+        rt.Sphere(rt.Point3(-4, 1, 0), 1.0, rt.Lambertian(rt.Color(0.4, 0.2, 0.1))),
+        rt.Sphere(rt.Point3(4, 1, 0), 1.0, rt.Metal(rt.Color(0.7, 0.6, 0.5), 0.0)),
+    ])
+    (sm, fix, st), (fb, _, stb), _ = both(renderer, oracle_mod, flat, 96, 54, 64)
+    assert np.array_equal(fix, fb) and st["rays_traced"] == stb["rays_traced"]
+    assert stb["end_depth"] > 0 and st["rays_traced"] > 6 * st["samples"]
+
+
+def test_tie_between_spheres_of_different_tiles(renderer, oracle_mod):
+    """Coincident spheres whose list positions are more than one 32-sphere filter tile apart (indices 3 and
+    70, and a third copy at 140): the later one must win the tie (mod.rs:61-67) although its candidates reach
+    the pooled exact tests in different rounds."""
+    spheres = [rt.Sphere(rt.Point3(0, -1000, 0), 1000, rt.Lambertian(rt.Color(0.5, 0.5, 0.5)))]
+    rng = np.random.default_rng(7)
+    for k in range(1, 160):
+        if k in (3, 70, 140):
+            m = [rt.Lambertian(rt.Color(0.9, 0.1, 0.1)), rt.Metal(rt.Color(0.1, 0.9, 0.1), 0.3), rt.Lambertian(rt.Color(0.1, 0.1, 0.9))][(3, 70, 140).index(k)]
+            spheres.append(rt.Sphere(rt.Point3(0, 1, 0), 1.0, m))
+        else:
+            c = rng.uniform(-9, 9, 3); c[1] = 0.2
+            spheres.append(rt.Sphere(c, 0.2, rt.Lambertian(rng.uniform(0.1, 0.9, 3))))
+    flat = hand_scene(spheres)
+    (sm, fix, st), (fb, _, stb), _ = both(renderer, oracle_mod, flat, 120, 68, 40)
+    assert np.array_equal(fix, fb) and st["rays_traced"] == stb["rays_traced"]
+    # the blue copy (index 140) is what the camera sees on the big sphere: its centre pixel is blue-ish
+    mean = fix.astype(np.float64) / 2.0 ** 32 / 40
+    cy, cx = 43, 60                                             # (rows count from the bottom: j = 43 is the middle of the big sphere)
+    assert mean[cy, cx, 2] > mean[cy, cx, 0]
+
+
+def test_zero_radius_is_rejected(book1_flat):
+    fresh = rt.Renderer(0)
+    try:
+        bad = book1_flat.copy()
+        bad["radius"][5] = 0.0
+        with pytest.raises(rt.RtiowHipError, match="radius must not be zero"):
+            fresh.upload_scene(bad)
+        with pytest.raises(rt.RtiowHipError, match="rt_upload_scene has not been called"):     # nothing half-uploaded
+            fresh.render(rt.book1_camera(8, 8), rt.make_params(8, 8, 1))
+    finally:
+        fresh.close()

@@ -33,6 +33,10 @@ def test_cfg2_accounting(cfg2, book1_flat):
     mean = fix.astype(np.float64) / 2.0 ** 32 / spp
     assert 0.0 <= mean.min() and mean.max() <= 1.0 + 1e-12          # sky <= 1 and albedos <= 1
     assert 0.3 < mean.mean() < 0.6
+    # A wave keeps the sums of at most 4 unfinished work blocks in LDS; a path of more than ~30 bounces holds its
+    # block open for longer than that, and the block's last samples then go to the frame buffer one by one.
+    # They exist at this size (6153 of these 81 M paths run the full 50 bounces) and they are rare.
+    assert 0 < st["direct_samples"] < st["samples"] // 1000
 
 
 @pytest.mark.parametrize("max_depth", [50, 5, 1])
@@ -151,12 +155,15 @@ def test_gpu_reproduces_the_reference_png_sky_rows(renderer, book1_flat):
 
 
 def test_all_scan_filters_give_the_same_bits(book1_flat, cfg2):
-    """The five filter implementations (VALU + scalar loads, f32 MFMA, bf16x3 MFMA, single-contraction
-    bf16x3 MFMA, bf16x2 tube) are five ways of discarding spheres the reference cannot hit: the frame
-    must not depend on which runs."""
+    """The filter implementations of the loaded library (product: VALU + scalar loads and the bf16x2 tube;
+    cross-check build, see test_gpu_crosscheck_modes.py: also f32 MFMA, bf16x3 MFMA, single-contraction
+    bf16x3 MFMA) are ways of discarding spheres the reference cannot hit: the frame must not depend on
+    which runs."""
+    from rtiow_amd import _ffi
     w, h, spp, fix, st = cfg2
     cands, roots = {}, set()
-    for mode in ("1", "2", "3", "4", "5"):
+    modes = ("1", "2", "3", "4", "5") if _ffi.has_crosscheck_modes() else ("1", "5")
+    for mode in modes:
         os.environ["RTIOW_SCAN_MODE"] = mode
         try:
             r = rt.Renderer(0)
@@ -166,13 +173,22 @@ def test_all_scan_filters_give_the_same_bits(book1_flat, cfg2):
         finally:
             os.environ.pop("RTIOW_SCAN_MODE")
         assert np.array_equal(got, fix), mode
-        assert st2["rays_traced"] == st["rays_traced"]
+        assert st2["rays_traced"] == st["rays_traced"] and st2["scan_mode"] == int(mode)
         roots.add(st2["exact_roots"])
         cands[mode] = st2["candidates"]
     assert len(roots) == 1                                  # the exact path sees the same real hits
-    assert cands["1"] <= cands["2"] * 1.2 and cands["2"] <= cands["3"] * 1.01   # looser KU keeps more
-    assert cands["4"] <= cands["3"] * 1.05                  # same KU, same slack: about as selective
-    assert cands["5"] <= cands["3"] * 1.25                  # a square tube instead of a slack-inflated cylinder
+    assert cands["1"] <= cands["5"] * 1.5                   # the f32 quadratic form and the square tube keep about as much
+    if "3" in cands:
+        assert cands["1"] <= cands["2"] * 1.2 and cands["2"] <= cands["3"] * 1.01   # looser KU keeps more
+        assert cands["4"] <= cands["3"] * 1.05              # same KU, same slack: about as selective
+        assert cands["5"] <= cands["3"] * 1.25              # a square tube instead of a slack-inflated cylinder
+    if not _ffi.has_crosscheck_modes():                     # the product build refuses the modes it does not carry
+        os.environ["RTIOW_SCAN_MODE"] = "3"
+        try:
+            with pytest.raises(rt.RtiowHipError, match="scan modes 1 and 5"):
+                rt.Renderer(0)
+        finally:
+            os.environ.pop("RTIOW_SCAN_MODE")
 
 
 def test_tenk_scene_full_size_properties(renderer):
