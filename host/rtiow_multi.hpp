@@ -1,0 +1,139 @@
+// rtiow_multi.hpp -- the reference's row parallelism (rayon over rows, src/main.rs:122-123, and the ordered
+// collect() at :139) across GPUs, natively: one rt_context per device, each driven by its own host thread
+// through the device-buffer form of the C ABI, rows dealt round-robin in tiles (rt_params.shard_index /
+// shard_count), ONE RCCL ncclGather of the exact u64 sums to the first device over xGMI, rows put back in
+// image order with strided device copies, resolve (Color::to_rgba + flip) on the first device.
+//
+// Because the Philox counter is keyed by the global pixel and sample index and the sums are exact integers,
+// the assembled frame equals the single-GPU frame bit for bit (tests/test_host_cpp.py).
+#pragma once
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rtiow_hip.h"
+
+namespace rtiow {
+
+struct ShardJob {
+    int device = 0;
+    rt_context *ctx = nullptr;
+    hipStream_t stream = nullptr;
+    uint64_t *d_fix = nullptr;          // [pad_rows][W][3], this shard's rows in ascending j
+    int rows = 0;
+    rt_stats stats{};
+    std::string err;
+};
+
+// rgba_out: [height][width][4], top row first (flip applied, as main.rs:141-145 leaves it).
+// Returns 0 on success; *err says what failed otherwise.
+inline int render_sharded(const std::vector<int> &devices, bool force_rccl, const std::vector<rt_sphere> &flat,
+                          const rt_camera &cam, const rt_params &base, uint8_t *rgba_out, rt_stats *stats_out,
+                          std::string *err)
+{
+    const int n = (int)devices.size();
+    const std::set<int> uniq(devices.begin(), devices.end());
+    const bool distinct = (int)uniq.size() == n;
+    const bool use_rccl = (distinct && n > 1) || (force_rccl && distinct);
+    if (!distinct && uniq.size() != 1) { *err = "a device list with repeats must name ONE device (RCCL cannot mix)"; return 1; }
+    const int W = base.width, H = base.height, T = base.tile_rows;
+    const int ntiles = (H + T - 1) / T;
+    const int pad_rows = ((ntiles + n - 1) / n) * T;                    // most rows any shard can own
+    const size_t row_words = (size_t)W * 3, pad_words = (size_t)pad_rows * row_words;
+
+    std::vector<ShardJob> jobs(n);
+    std::vector<ncclComm_t> comms(n, nullptr);
+    if (use_rccl) {
+        const ncclResult_t r = ncclCommInitAll(comms.data(), n, devices.data());
+        if (r != ncclSuccess) { *err = std::string("ncclCommInitAll: ") + ncclGetErrorString(r); return 1; }
+    }
+    uint64_t *d_staging = nullptr;                                      // root: the gathered parts [n][pad_rows][W][3]
+    auto hip_ok = [](hipError_t e, const char *what, std::string *msg) {
+        if (e == hipSuccess) return true;
+        *msg = std::string(what) + ": " + hipGetErrorString(e);
+        return false;
+    };
+    if (!hip_ok(hipSetDevice(devices[0]), "hipSetDevice", err)) return 1;
+    if (use_rccl && !hip_ok(hipMalloc((void **)&d_staging, (size_t)n * pad_words * sizeof(uint64_t)), "hipMalloc staging", err)) return 1;
+
+    auto work = [&](int k) {
+        ShardJob &J = jobs[k];
+        J.device = devices[k];
+        rt_params p = base;
+        p.shard_index = k; p.shard_count = n;
+        int rc = 0;
+        auto fail = [&](const char *what) { J.err = std::string(what) + " (shard " + std::to_string(k) + "): " + rt_last_error(); };
+        if ((rc = rt_create(J.device, &J.ctx))) return fail("rt_create");
+        if ((rc = rt_upload_scene(J.ctx, flat.data(), (int32_t)flat.size()))) return fail("rt_upload_scene");
+        int32_t rows = 0;
+        if ((rc = rt_shard_rows(&p, &rows))) return fail("rt_shard_rows");
+        J.rows = rows;
+        if (!hip_ok(hipSetDevice(J.device), "hipSetDevice", &J.err)) return;
+        if (!hip_ok(hipStreamCreateWithFlags(&J.stream, hipStreamNonBlocking), "hipStreamCreate", &J.err)) return;
+        if (!hip_ok(hipMalloc((void **)&J.d_fix, pad_words * sizeof(uint64_t)), "hipMalloc", &J.err)) return;
+        if (!hip_ok(hipMemsetAsync(J.d_fix, 0, pad_words * sizeof(uint64_t), J.stream), "hipMemsetAsync", &J.err)) return;
+        if ((rc = rt_render_device(J.ctx, &cam, &p, J.d_fix, J.stream))) return fail("rt_render_device");   // main.rs:122-136
+        if (use_rccl) {
+            // THE collective of the path: every rank sends its padded rows, rank 0 receives all of them
+            const ncclResult_t r = ncclGather(J.d_fix, d_staging, pad_words, ncclUint64, 0, comms[k], J.stream);
+            if (r != ncclSuccess) { J.err = std::string("ncclGather: ") + ncclGetErrorString(r); return; }
+        }
+        if (!hip_ok(hipStreamSynchronize(J.stream), "hipStreamSynchronize", &J.err)) return;
+        if ((rc = rt_last_stats(J.ctx, &J.stats))) return fail("rt_last_stats");
+    };
+    std::vector<std::thread> threads;
+    for (int k = 0; k < n; ++k) threads.emplace_back(work, k);
+    for (auto &t : threads) t.join();
+    for (const ShardJob &J : jobs) if (!J.err.empty()) { *err = J.err; return 1; }
+
+    // rank 0: rows back into image order.  Shard k owns tiles k, k+n, ...: tile t of the image is local tile
+    // t / n of shard t % n, so one strided copy per (shard, row within a tile) rebuilds the frame.
+    uint64_t *d_full = nullptr;
+    uint8_t *d_rgba = nullptr;
+    if (!hip_ok(hipSetDevice(devices[0]), "hipSetDevice", err)) return 1;
+    if (!hip_ok(hipMalloc((void **)&d_full, (size_t)H * row_words * sizeof(uint64_t)), "hipMalloc frame", err)) return 1;
+    if (!hip_ok(hipMalloc((void **)&d_rgba, (size_t)H * W * 4), "hipMalloc rgba", err)) return 1;
+    hipStream_t s0 = jobs[0].stream;
+    const size_t row_bytes = row_words * sizeof(uint64_t);
+    for (int k = 0; k < n; ++k) {
+        const uint64_t *src = use_rccl ? d_staging + (size_t)k * pad_words : jobs[k].d_fix;
+        for (int t = k; t < ntiles; t += n) {
+            const int lt = t / n;                                        // local tile of shard k
+            const int lo = t * T, cnt = std::min(T, H - lo);
+            if (!hip_ok(hipMemcpyAsync(d_full + (size_t)lo * row_words, src + (size_t)lt * T * row_words,
+                                       (size_t)cnt * row_bytes, hipMemcpyDeviceToDevice, s0), "hipMemcpyAsync rows", err)) return 1;
+        }
+    }
+    long long spp_total = base.spp;
+    if (rt_resolve_rgba8_device(jobs[0].ctx, d_full, W, H, spp_total, 1, d_rgba, s0)) { *err = rt_last_error(); return 1; }
+    if (!hip_ok(hipMemcpyAsync(rgba_out, d_rgba, (size_t)H * W * 4, hipMemcpyDeviceToHost, s0), "hipMemcpyAsync rgba", err)) return 1;
+    if (!hip_ok(hipStreamSynchronize(s0), "hipStreamSynchronize", err)) return 1;
+
+    if (stats_out) {
+        *stats_out = jobs[0].stats;
+        for (int k = 1; k < n; ++k) {
+            stats_out->samples += jobs[k].stats.samples; stats_out->rays_traced += jobs[k].stats.rays_traced;
+            stats_out->sphere_tests += jobs[k].stats.sphere_tests;
+            stats_out->kernel_ms = std::max(stats_out->kernel_ms, jobs[k].stats.kernel_ms);
+        }
+    }
+    (void)hipFree(d_full); (void)hipFree(d_rgba); (void)hipFree(d_staging);
+    for (int k = 0; k < n; ++k) {
+        (void)hipSetDevice(jobs[k].device);
+        (void)hipFree(jobs[k].d_fix);
+        if (jobs[k].stream) (void)hipStreamDestroy(jobs[k].stream);
+        rt_destroy(jobs[k].ctx);
+        if (comms[k]) ncclCommDestroy(comms[k]);
+    }
+    return 0;
+}
+
+} // namespace rtiow

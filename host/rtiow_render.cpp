@@ -4,12 +4,20 @@
 //
 //   rtiow_render [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--scene-seed S]
 //                [--grid LO HI] [--device K] [--out image.ppm] [--dump-scene scene.bin] [--scene scene.bin]
+//                [--devices 0,1,..  [--tile-rows T] [--force-rccl]]
+//
+// --devices: the frame's rows are dealt round-robin to one rt_context per listed device, each driven by
+// its own host thread, and gathered with ONE RCCL ncclGather to the first device (host/rtiow_multi.hpp).
+// A device may be listed more than once (two contexts on one GPU from two threads: the threading rule of
+// include/rtiow_hip.h); RCCL does not allow that within a communicator, so such a list gathers with plain
+// device copies.  --force-rccl runs the RCCL path even for a single device.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 
 #include "rtiow_host.hpp"
+#include "rtiow_multi.hpp"
 
 static int die(const char *what, int rc)
 {
@@ -22,6 +30,9 @@ int main(int argc, char **argv)
     int width = 400, height = 225, spp = 10, depth = 50, device = 0, lo = -11, hi = 11;
     unsigned long long seed = 1, scene_seed = 1;
     std::string out = "image.ppm", dump, scene_file;
+    std::vector<int> devices;                    // --devices 0,1,...: one context + host thread per entry
+    bool force_rccl = false;
+    int tile_rows = 1;
     for (int i = 1; i < argc; ++i) {
         auto arg = [&](const char *n) { return !std::strcmp(argv[i], n) && i + 1 < argc; };
         if (arg("--width")) width = std::atoi(argv[++i]);
@@ -32,6 +43,9 @@ int main(int argc, char **argv)
         else if (arg("--scene-seed")) scene_seed = std::strtoull(argv[++i], nullptr, 0);
         else if (arg("--device")) device = std::atoi(argv[++i]);
         else if (arg("--out")) out = argv[++i];
+        else if (arg("--devices")) { for (char *t = std::strtok(argv[++i], ","); t; t = std::strtok(nullptr, ",")) devices.push_back(std::atoi(t)); }
+        else if (arg("--tile-rows")) tile_rows = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--force-rccl")) force_rccl = true;
         else if (arg("--dump-scene")) dump = argv[++i];
         else if (arg("--scene")) scene_file = argv[++i];
         else if (!std::strcmp(argv[i], "--grid") && i + 2 < argc) { lo = std::atoi(argv[++i]); hi = std::atoi(argv[++i]); }
@@ -60,24 +74,35 @@ int main(int argc, char **argv)
     }
     const rtiow::Camera cam(rtiow::Point3(13, 2, 3), rtiow::Point3(0, 0, 0), rtiow::Vec3(0, 1, 0), 20.0,
                             (double)width / (double)height, 0.1, 10.0);             // main.rs:108-118
-    rt_context *ctx = nullptr;
-    int rc = rt_create(device, &ctx);
-    if (rc) return die("rt_create", rc);
-    rc = rt_upload_scene(ctx, flat.data(), (int32_t)flat.size());
-    if (rc) return die("rt_upload_scene", rc);
     rt_params p{};
     p.width = width; p.height = height; p.spp = spp; p.sample_begin = 0; p.max_depth = depth;
     p.t_min = 0.0001; p.seed = seed; p.tile_rows = 8; p.shard_index = 0; p.shard_count = 1; p.flags = 0;
     const size_t npix = (size_t)width * height;
-    std::vector<uint64_t> fix(npix * 3);
     const rt_camera rc_cam = cam.flat();
-    rt_stats st{};
-    rc = rt_render(ctx, &rc_cam, &p, nullptr, fix.data(), &st);                      // main.rs:122-136
-    if (rc) return die("rt_render", rc);
     std::vector<uint8_t> rgba(npix * 4);
-    rc = rt_resolve_rgba8(ctx, fix.data(), width, height, spp, 1, rgba.data());      // main.rs:137,141-145
-    if (rc) return die("rt_resolve_rgba8", rc);
-    rt_destroy(ctx);
+    rt_stats st{};
+    if (!devices.empty()) {
+        // one rt_context per listed device, each driven by its own host thread; rows dealt round-robin;
+        // one RCCL gather of the exact sums to the first device (main.rs:122-123 + the ordered collect() :139)
+        p.tile_rows = tile_rows;
+        std::string err;
+        if (rtiow::render_sharded(devices, force_rccl, flat, rc_cam, p, rgba.data(), &st, &err)) {
+            std::fprintf(stderr, "render_sharded failed: %s\n", err.c_str());
+            return 1;
+        }
+    } else {
+        rt_context *ctx = nullptr;
+        int rc = rt_create(device, &ctx);
+        if (rc) return die("rt_create", rc);
+        rc = rt_upload_scene(ctx, flat.data(), (int32_t)flat.size());
+        if (rc) return die("rt_upload_scene", rc);
+        std::vector<uint64_t> fix(npix * 3);
+        rc = rt_render(ctx, &rc_cam, &p, nullptr, fix.data(), &st);                  // main.rs:122-136
+        if (rc) return die("rt_render", rc);
+        rc = rt_resolve_rgba8(ctx, fix.data(), width, height, spp, 1, rgba.data());  // main.rs:137,141-145
+        if (rc) return die("rt_resolve_rgba8", rc);
+        rt_destroy(ctx);
+    }
     FILE *f = std::fopen(out.c_str(), "wb");
     if (!f) { std::perror(out.c_str()); return 1; }
     std::fprintf(f, "P6\n%d %d\n255\n", width, height);

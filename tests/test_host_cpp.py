@@ -50,3 +50,21 @@ def test_cpp_cli_reads_a_scene_file(tmp_path, renderer):
     renderer.upload_scene(world)
     _, fix, _ = renderer.render(rt.book1_camera(96, 54), rt.make_params(96, 54, 3))
     assert np.array_equal(rt.read_ppm(out), renderer.resolve_rgba8(fix, 3, flip=True)[:, :, :3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--devices", "0,0"], ["--devices", "0,0,0", "--tile-rows", "7"],
+                                   ["--devices", "0", "--force-rccl"]])
+def test_cpp_sharded_render_equals_the_single_context_image(tmp_path, extra):
+    """host/rtiow_multi.hpp: one rt_context per listed device, each on its own host thread (here: two or three
+    contexts on device 0 rendering their shards CONCURRENTLY -- the threading rule of include/rtiow_hip.h:
+    distinct contexts may be used from distinct threads at the same time), rows gathered and put back in
+    image order, one resolve.  The result must be the single-context image byte for byte.  A list of distinct
+    devices gathers with RCCL ncclGather; with one GPU here that path runs as a communicator of one
+    (--force-rccl)."""
+    single, sharded = str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm")
+    size = ["--width", "300", "--height", "169", "--spp", "40"]
+    subprocess.run([_cli(), *size, "--out", single], check=True, capture_output=True)
+    r = subprocess.run([_cli(), *size, *extra, "--out", sharded], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(single, "rb").read() == open(sharded, "rb").read()
