@@ -154,6 +154,27 @@ def test_gpu_reproduces_the_reference_png_sky_rows(renderer, book1_flat):
     assert np.abs(m - np.array(fx["image_mean_rgb"])).max() < 15
 
 
+def test_gpu_reproduces_what_the_reference_png_holds_about_the_big_spheres(renderer, book1_flat):
+    """tests/png_pins.py on the GPU render (1200x800, 3:2, 48 spp): the sky mirrored in the fuzz-0 Metal sphere
+    within 1 of the PNG, the silhouettes of the three hard-coded spheres and the ground's horizon where the PNG
+    has them, the mean colour of the Lambertian sphere's sky-facing patch -- the reference's own artefact
+    pinning Sphere::hit, HitRecord::new, Metal::scatter/reflect and Lambertian::scatter on the device."""
+    import png_pins
+    fx = png_pins.fixture()
+    w, h, spp = 1200, 800, 48
+    cam = rt.Camera(rt.Point3(13, 2, 3), rt.Point3(0, 0, 0), rt.Vec3(0, 1, 0), 20.0, 3.0 / 2.0, 0.1, 10.0)
+    renderer.upload_scene(book1_flat)
+    _, fix, _ = renderer.render(cam, rt.make_params(w, h, spp))
+    rgb = renderer.resolve_rgba8(fix, spp, flip=True)[..., :3]
+    renderer.upload_scene(book1_flat[:0])                          # the empty scene: the sky reference
+    _, fix0, _ = renderer.render(cam, rt.make_params(w, h, 4))
+    sky = renderer.resolve_rgba8(fix0, 4, flip=True)[..., :3]
+    y0, y1 = fx["rows_scanned"]
+    png_pins.check_metal_cap(fx, lambda y: rgb[y])
+    png_pins.check_silhouettes_and_horizon(fx, png_pins.nonsky_mask(fx, rgb[y0:y1], sky[y0:y1]))
+    png_pins.check_lambertian_patch(fx, rgb[y0:y1])
+
+
 def test_all_scan_filters_give_the_same_bits(book1_flat, cfg2):
     """The filter implementations of the loaded library (product: VALU + scalar loads and the bf16x2 tube;
     cross-check build, see test_gpu_crosscheck_modes.py: also f32 MFMA, bf16x3 MFMA, single-contraction
