@@ -55,6 +55,7 @@ struct rt_context {
     uint4 *d_btube = nullptr;      // [tiles/2 + 1][64] MODE 5 (tube filter) B operands
     float *d_rtube = nullptr;      // [tiles/2 + 1][32] MODE 5 per-sphere bounds
     float tube_rho = 1.0f;         // MODE 5 radius floor
+    float box_lo[3] = {1.0f, 1.0f, 1.0f}, box_hi[3] = {-1.0f, -1.0f, -1.0f}, box_scale = 0.0f;   // MODE 5: box of the scanned spheres
 #ifdef RTIOW_CROSSCHECK_MODES
     float *d_bmat = nullptr;       // [tiles][64] MFMA B operand of the filter
     float *d_kpt = nullptr;        // [tiles][16] K' per sphere
@@ -442,6 +443,25 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
         std::vector<char> never(n > 0 ? n : 1, 0);
         for (int e = 0; e < ctx->n_always; ++e) never[ctx->always_idx[e]] = 1;
         ctx->tube_rho = tube_radius_floor(spheres, n, never.data());
+        // the box around every sphere the tables hold (rt_device.hpp, ray_may_reach_box), rounded outwards
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = 0; i < n; ++i) {
+            if (never[i]) continue;
+            const double r = std::fabs(spheres[i].radius);
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = std::min(lo[k], spheres[i].center[k] - r);
+                hi[k] = std::max(hi[k], spheres[i].center[k] + r);
+            }
+        }
+        ctx->box_scale = 0.0f;
+        for (int k = 0; k < 3; ++k) {
+            if (lo[k] > hi[k]) { ctx->box_lo[k] = 1.0f; ctx->box_hi[k] = -1.0f; continue; }     // no scanned sphere
+            float fl = (float)lo[k], fh = (float)hi[k];
+            if ((double)fl > lo[k]) fl = std::nextafterf(fl, -INFINITY);
+            if ((double)fh < hi[k]) fh = std::nextafterf(fh, INFINITY);
+            ctx->box_lo[k] = fl; ctx->box_hi[k] = fh;
+            ctx->box_scale += std::max(std::fabs(fl), std::fabs(fh));
+        }
         for (size_t t = 0; t < ttc; ++t) {
             const rt_sphere *col[32];
             for (int c = 0; c < 32; ++c) {
@@ -588,6 +608,11 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.bmat16 = ctx->d_bmat16; kp.kpt16 = ctx->d_kpt16; kp.bmatL = ctx->d_bmatL;
 #endif
     kp.btube = ctx->d_btube; kp.rtube = ctx->d_rtube; kp.tube_rho = ctx->tube_rho;
+    for (int k = 0; k < 3; ++k) { kp.box_lo[k] = ctx->box_lo[k]; kp.box_hi[k] = ctx->box_hi[k]; }
+    kp.box_scale = ctx->box_scale;
+    if (env_int("RTIOW_NO_BOX_CULL", 0)) {          // diagnostic A/B: a box no ray can miss
+        for (int k = 0; k < 3; ++k) { kp.box_lo[k] = -1e30f; kp.box_hi[k] = 1e30f; }
+    }
     kp.n_always = ctx->n_always;
     for (int e = 0; e < 8; ++e) kp.always_idx[e] = ctx->always_idx[e];
     kp.fix = (unsigned long long *)d_fix;

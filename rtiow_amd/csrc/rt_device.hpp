@@ -72,8 +72,10 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)M0 * c0;      // hi and lo of one 32x32 product
         const uint64_t p1 = (uint64_t)M1 * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        // hi ^ counter ^ key as ONE v_bitop3_b32 (truth table 0x96 = three-input XOR; gfx950 has no v_xor3 and the
+        // compiler emits two v_xor_b32 for the plain expression: 40 of a block's ~57 vector instructions were XORs)
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
         c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
         k0 += W0; k1 += W1;
     }
@@ -347,6 +349,37 @@ __device__ __forceinline__ void lifted_stage_operands(uint4 *stage, int lane, co
 constexpr float kTubeBasisErr = 64.0f * kUnitRoundoff;
 constexpr float kTubeCenterErr = 640.0f * kUnitRoundoff;
 constexpr float kTubeOriginErr = 128.0f * kUnitRoundoff;
+
+// Can the ray o + t d, t > 0, come within reach of the axis-aligned box [lo, hi] that holds every scanned sphere
+// (host: rounded outwards)?  Slab test in f32, biased to answer "yes":
+//   * o and d are rounded to f32 (6e-8 relative each): the line they define stays within 6e-8 (|o| + L) of the true
+//     one at distance L, and the box can only matter for L <= |o| + its own size, so it is grown by
+//     e = 1e-6 (|o|_1 + scale) on every side;
+//   * v_rcp_f32 and the products put <= 3e-7 relative error on each slab parameter: the interval test keeps a
+//     ray unless the exit parameter lies below 0.9999 of the entry parameter;
+//   * a direction component of magnitude < 1e-30, a non-finite value or |o|, |d| beyond 1e15: always "yes"
+//     (a NaN anywhere makes the final comparison false, which also answers "yes").
+// An empty box (lo > hi: no scanned sphere) answers "no" for every ordinary ray.
+__device__ __forceinline__ bool ray_may_reach_box(D3 o, D3 d, const float (&lo)[3], const float (&hi)[3], float scale)
+{
+    const float of[3] = {(float)o.x, (float)o.y, (float)o.z};
+    const float df[3] = {(float)d.x, (float)d.y, (float)d.z};
+    const float o1 = __builtin_fabsf(of[0]) + __builtin_fabsf(of[1]) + __builtin_fabsf(of[2]);
+    const float e = 1e-6f * (o1 + scale);
+    float t_in = 0.0f, t_out = __builtin_inff();
+    float dmin = __builtin_inff(), dmax = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float inv = __builtin_amdgcn_rcpf(df[k]);
+        const float a = ((lo[k] - e) - of[k]) * inv, b = ((hi[k] + e) - of[k]) * inv;
+        t_in = __builtin_fmaxf(t_in, __builtin_fminf(a, b));
+        t_out = __builtin_fminf(t_out, __builtin_fmaxf(a, b));
+        dmin = __builtin_fminf(dmin, __builtin_fabsf(df[k]));
+        dmax = __builtin_fmaxf(dmax, __builtin_fabsf(df[k]));
+    }
+    const bool sane = dmin > 1e-30f && dmax < 1e15f && o1 < 1e15f;
+    return !sane || !(t_out < t_in * 0.9999f);
+}
 
 struct TubeRay {
     float u[2][3];      // lambda * u_k

@@ -67,6 +67,10 @@ struct KParams {
     const uint4 *btube;        // [tiles/2 + 1][64] MODE 5 B operands: 32 spheres x 16 K-slots (rt_device.hpp)
     const float *rtube;        // [tiles/2 + 1][32] MODE 5 per-sphere bound max(R, rho); negative: never kept
     float tube_rho;            // MODE 5 radius floor
+    // MODE 5: axis-aligned box around every sphere of the filter tables (the always-exact ones excluded), rounded
+    // outwards; a ray that cannot reach it skips the scan (a wave whose rays all skip it skips the tile loop).
+    // box_lo > box_hi: no such sphere.  box_scale = sum over axes of max(|lo|, |hi|).
+    float box_lo[3], box_hi[3], box_scale;
     int32_t n_tiles;
     int32_t n_always;          // spheres that skip the filter and are always tested exactly
     int32_t always_idx[8];
@@ -151,12 +155,9 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
     __shared__ unsigned long long s_best[MATRIX ? kBlock : 1];
     __shared__ unsigned int s_bidx[MATRIX ? kBlock : 1];
     // Per wave, the exact sums (u64 fixed point) of up to kRingDepth unfinished blocks, [pixel slot][channel]; a block is
-    // written to the frame buffer once, by whichever pass finishes its last sample.  s_rcnt: 0 = free, else
-    // 1 + (kItemBlock - items of the block) + samples finished, so every block completes at kItemBlock + 1;
-    // s_rseq: sequence number of the block that owns the entry; s_rpix: its first pixel (compact index).
+    // written to the frame buffer once, by whichever pass finishes its last sample (how many samples each block
+    // still waits for is wave-uniform state in SGPRs).  s_rpix: first pixel (compact index) of the entry's block.
     __shared__ unsigned long long s_ring[kBlock / 64][kRingDepth][kRingSlots * 3];
-    __shared__ unsigned int s_rcnt[kBlock / 64][kRingDepth];
-    __shared__ unsigned int s_rseq[kBlock / 64][kRingDepth];
     __shared__ unsigned int s_rpix[kBlock / 64][kRingDepth];
     __shared__ unsigned int s_live[DIAG ? kBlock / 64 : 1][DIAG ? 64 : 1];    // DIAG: rays per bounce index, per wave
     // so does the path throughput (contract C3): read and written once per bounce
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
     {   // this wave's block sums and their bookkeeping (own wave only: no barrier needed)
         unsigned long long *z = &s_ring[tid >> 6][0][0];
         for (int k = lane; k < kRingDepth * kRingSlots * 3; k += 64) z[k] = 0ull;
-        if (lane < kRingDepth) { s_rcnt[tid >> 6][lane] = 0u; s_rseq[tid >> 6][lane] = 0xFFFFFFFFu; s_rpix[tid >> 6][lane] = 0u; }
+        if (lane < kRingDepth) s_rpix[tid >> 6][lane] = 0u;
     }
     if (DIAG) s_live[tid >> 6][tid & 63] = 0u;                          // this wave's row only
     // number of set bits of a wave mask below this lane (v_mbcnt: no per-lane 64-bit mask to keep)
@@ -202,7 +203,11 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
     uint32_t blk_next = 0, blk_end = 0, blk_seq = 0xFFFFFFFFu, blk_pix0 = 0, blk_s0 = 0, blk_rr0 = 0, blk_i0 = 0;
     bool queue_empty = false;
     unsigned long long *ring_w = &s_ring[tid >> 6][0][0];
-    unsigned int *rcnt_w = &s_rcnt[tid >> 6][0], *rseq_w = &s_rseq[tid >> 6][0], *rpix_w = &s_rpix[tid >> 6][0];
+    unsigned int *rpix_w = &s_rpix[tid >> 6][0];
+    // samples the wave's four youngest blocks still wait for (wave-uniform; index = age: 0 is the current block
+    // blk_seq, k is block blk_seq - k, whose sums are ring entry (blk_seq - k) % kRingDepth); 0 = complete or none
+    uint32_t rem0 = 0, rem1 = 0, rem2 = 0, rem3 = 0;
+    static_assert(kRingDepth == 4, "the block counters are written out for a ring of 4");
     // one block's sums -> frame buffer (wave-uniform call; `e` uniform): lane l < 24 holds (pixel slot l/3, channel l%3),
     // which are 24 consecutive u64 of the frame buffer; zero sums (unused slots, black pixels) are not sent
     auto flush_ring = [&](uint32_t e) {
@@ -213,7 +218,6 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 ring_w[e * (kRingSlots * 3) + lane] = 0ull;
             }
         }
-        if (lane == 0) rcnt_w[e] = 0u;
         __builtin_amdgcn_wave_barrier();
     };
 
@@ -280,12 +284,12 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 blk_next = 0u; blk_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_items);
                 blk_seq += 1u;
                 if (P.use_ring) {
-                    // the ring entry may still belong to a block kRingDepth reservations ago that has samples in flight
-                    // (a path of > ~30 bounces): what it has collected goes out now, and its remaining samples will
-                    // find the entry re-assigned and go to the frame buffer directly ("orphans")
-                    const uint32_t e = blk_seq & (uint32_t)(kRingDepth - 1);
-                    if (__builtin_amdgcn_readfirstlane((int)rcnt_w[e]) != 0) flush_ring(e);
-                    if (lane == 0) { rcnt_w[e] = 1u + ((uint32_t)kItemBlock - n_items); rseq_w[e] = blk_seq & 0x0FFFFFFFu; rpix_w[e] = blk_pix0; }
+                    // The oldest of the four blocks leaves the ring.  If a path of > ~30 bounces still holds it open,
+                    // what it has collected goes out now and its remaining samples will go to the frame buffer
+                    // directly when they finish ("orphans": their age is then >= kRingDepth).
+                    if (rem3 != 0u) flush_ring(blk_seq & (uint32_t)(kRingDepth - 1));
+                    rem3 = rem2; rem2 = rem1; rem1 = rem0; rem0 = blk_end;
+                    if (lane == 0) rpix_w[blk_seq & (uint32_t)(kRingDepth - 1)] = blk_pix0;
                     __builtin_amdgcn_wave_barrier();
                 }
             }
@@ -578,18 +582,24 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
             const int nt = P.n_tiles;                   // even; the tables hold nt + 2 tiles
 
             if constexpr (TUBE) {
-                const TubeRay T = alive ? make_tube(o, d, P.tube_rho) : no_tube_ray();
+                if (alive)
+                    for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e]); }
+                // A ray that cannot reach the box around the scanned spheres (a camera ray into the sky, a bounce
+                // that leaves the scene) has nothing to scan; a wave in which NO ray can -- the waves working on
+                // sky pixels, where every lane starts a new camera ray in every pass -- skips operands, tile
+                // loop and pool altogether.  Conservative like the filter itself: never changes a result.
+                const bool scan = alive && ray_may_reach_box(o, d, P.box_lo, P.box_hi, P.box_scale);
+                const unsigned long long scan_mask = __ballot(scan);
+                if (scan_mask != 0ull) {
+                const TubeRay T = scan ? make_tube(o, d, P.tube_rho) : no_tube_ray();
                 bf16x8 A[4];
                 {
                     uint32_t w[2][8];
                     tube_a_words(T, w);
                     tube_stage_operands(reinterpret_cast<uint4 *>(bits_w), lane, w, A);
                 }
-                if (alive) {
-                    for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e]); }
-                    // outside the analysed range: everything is tested exactly
-                    if (!T.sane) for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i); }
-                }
+                // outside the analysed range: everything is tested exactly
+                if (scan && !T.sane) for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i); }
                 typedef float f32x16 __attribute__((ext_vector_type(16)));
                 const int ntt = nt >> 1;                    // tiles of 32 spheres; the tables hold ntt + 1
                 const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
@@ -605,9 +615,9 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 };
                 const int col32 = lane & 31, hh = lane >> 5;
                 const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                // which 16-ray groups hold at least one path (wave-uniform)
-                const unsigned groups = ((alive_mask & 0xFFFFull) ? 1u : 0u) | ((alive_mask & 0xFFFF0000ull) ? 2u : 0u) |
-                                        ((alive_mask & 0xFFFF00000000ull) ? 4u : 0u) | ((alive_mask >> 48) ? 8u : 0u);
+                // which 16-ray groups hold at least one ray to scan (wave-uniform)
+                const unsigned groups = ((scan_mask & 0xFFFFull) ? 1u : 0u) | ((scan_mask & 0xFFFF0000ull) ? 2u : 0u) |
+                                        ((scan_mask & 0xFFFF00000000ull) ? 4u : 0u) | ((scan_mask >> 48) ? 8u : 0u);
                 // results of one MFMA: acc[8bb + j] / acc[8bb + 4 + j] are h_1 / h_2 of ray 16G + 8bb + 4hh + j
                 // against sphere 32 t + col32; kept iff max(|h_1|, |h_2|) <= bound
                 auto look_tube = [&](int G, const f32x16 &acc, float bound, int wrel) {
@@ -709,6 +719,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                     enumerate(seg0);
                 }
                 finish_pool();
+                }   // scan_mask != 0
             }
 #ifdef RTIOW_CROSSCHECK_MODES
             else if constexpr (LIFTED) {
@@ -1009,26 +1020,48 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
         }
         // ---- (f) finished samples -> their block's sums (LDS) or, without a ring entry, the frame buffer ----
         {
-            bool completes = false, direct = false;
-            const uint32_t e = (my_blk >> 4) & (uint32_t)(kRingDepth - 1);
+            // age of this lane's block among the wave's blocks (0 = the current one); blocks of age >= kRingDepth have
+            // lost their ring entry (sequence numbers compare modulo 2^28: the ring is 4 deep)
+            const uint32_t age = (blk_seq - (my_blk >> 4)) & 0x0FFFFFFFu;
+            const bool direct = finished && !(P.use_ring && age < (uint32_t)kRingDepth);
+            const bool ringed = finished && !direct;
             if (finished) {
                 const unsigned long long q0 = quantize(radiance.x), q1 = quantize(radiance.y), q2 = quantize(radiance.z);
-                direct = !(P.use_ring && rseq_w[e] == (my_blk >> 4));
-                if (!direct) {
-                    unsigned long long *acc = ring_w + e * (kRingSlots * 3) + (my_blk & 15u) * 3u;
+                if (ringed) {
+                    unsigned long long *acc = ring_w + ((my_blk >> 4) & (uint32_t)(kRingDepth - 1)) * (kRingSlots * 3) + (my_blk & 15u) * 3u;
                     atomicAdd(acc + 0, q0); atomicAdd(acc + 1, q1); atomicAdd(acc + 2, q2);
-                    completes = atomicAdd(&rcnt_w[e], 1u) == (uint32_t)kItemBlock;      // this was the block's last sample
                 } else {                                            // spp < kRingMinSpp, or an orphan of a long-gone block
                     unsigned long long *px = P.fix + (size_t)pix_local * 3u;
                     atomicAdd(px + 0, q0); atomicAdd(px + 1, q1); atomicAdd(px + 2, q2);
                 }
             }
             n_direct += (uint32_t)__popcll(__ballot(direct));
-            unsigned long long cm = __ballot(completes);
-            while (cm != 0ull) {                                    // (rare: once per block)
-                const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)__builtin_ctzll(cm));
-                flush_ring(ce);
-                cm &= ~__ballot(completes && e == ce);
+            unsigned long long fm = __ballot(ringed);
+            if (fm != 0ull) {
+                // count the finished samples per block (nearly always the current and the previous one), and write
+                // out the blocks that have just received their last sample (LDS operations of a wave execute in
+                // program order: the adds above are in the sums flush_ring reads)
+                __builtin_amdgcn_wave_barrier();
+                const unsigned long long m0 = __ballot(ringed && age == 0u);
+                rem0 -= (uint32_t)__popcll(m0);
+                if (m0 != 0ull && rem0 == 0u) flush_ring(blk_seq & 3u);
+                fm &= ~m0;
+                if (fm != 0ull) {
+                    const unsigned long long m1 = __ballot(ringed && age == 1u);
+                    rem1 -= (uint32_t)__popcll(m1);
+                    if (m1 != 0ull && rem1 == 0u) flush_ring((blk_seq - 1u) & 3u);
+                    fm &= ~m1;
+                    if (fm != 0ull) {
+                        const unsigned long long m2 = __ballot(ringed && age == 2u);
+                        rem2 -= (uint32_t)__popcll(m2);
+                        if (m2 != 0ull && rem2 == 0u) flush_ring((blk_seq - 2u) & 3u);
+                        fm &= ~m2;
+                        if (fm != 0ull) {
+                            rem3 -= (uint32_t)__popcll(fm);
+                            if (rem3 == 0u) flush_ring((blk_seq - 3u) & 3u);
+                        }
+                    }
+                }
             }
         }
         n_samples += (uint32_t)__popcll(__ballot(finished));
@@ -1036,8 +1069,10 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
     }
     // every block of this wave has finished its last sample and has been written out; a ring entry that
     // still holds something here would be a bookkeeping error -- its sums go out rather than get lost
-    for (uint32_t e = 0; e < (uint32_t)kRingDepth; ++e)
-        if (__builtin_amdgcn_readfirstlane((int)rcnt_w[e]) != 0) flush_ring(e);
+    if (rem0 != 0u) flush_ring(blk_seq & 3u);
+    if (rem1 != 0u) flush_ring((blk_seq - 1u) & 3u);
+    if (rem2 != 0u) flush_ring((blk_seq - 2u) & 3u);
+    if (rem3 != 0u) flush_ring((blk_seq - 3u) & 3u);
 
         // (end of the bounce loop body is stamped at the top of the next iteration as phase 4)
     // wave totals -> device counters
