@@ -45,10 +45,19 @@ static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* Event stream of one (pixel, sample).  `explicit_u` (unit tests only)
- * replaces the Philox words by a caller-supplied list of uniforms. */
+/* Random words of one (pixel, sample): the Philox blocks B_e = philox(pixel, sample, e, 0), e = 0, 1, ...,
+ * consumed in RUNS.  A run takes consecutive words, block after block; when it ends (rng_end_run) the rest of
+ * its last block is dropped and the next run starts at a fresh block.  Runs:
+ *   camera   B_0 = (u jitter, v jitter, lens x, lens y); every further unit-disk try (vec3.rs:62-63) takes the
+ *            next two words -- two tries per block;
+ *   a Lambertian/Metal scatter: unit-sphere tries (vec3.rs:31-33) of three consecutive words -- four tries per
+ *            three blocks;
+ *   a Dialectric's reflectance draw (materials.rs:96): one word, one block, only if can_refract.
+ * `explicit_u` (unit tests only) replaces the words by a caller-supplied list of uniforms. */
 typedef struct {
     uint32_t k0, k1, pixel, sample, event;
+    uint32_t w[4];
+    int have;               /* words of the current block not yet taken: w[4 - have .. 3] */
     const double *explicit_u;
     int explicit_n, explicit_used;
 } oracle_rng;
@@ -56,12 +65,12 @@ typedef struct {
 static inline void rng_init(oracle_rng *r, uint64_t seed, uint32_t pixel, uint32_t sample)
 {
     r->k0 = (uint32_t)seed; r->k1 = (uint32_t)(seed >> 32);
-    r->pixel = pixel; r->sample = sample; r->event = 0;
+    r->pixel = pixel; r->sample = sample; r->event = 0; r->have = 0;
     r->explicit_u = 0; r->explicit_n = 0; r->explicit_used = 0;
 }
 
-/* Next event: fills `count` uniforms (as doubles holding k*2^-24 values). */
-static inline void rng_event(oracle_rng *r, int count, double *u)
+/* Next `count` words of the current run as uniforms k * 2^-24 (exact in f64). */
+static inline void rng_take(oracle_rng *r, int count, double *u)
 {
     if (r->explicit_u) {
         for (int i = 0; i < count; ++i) {
@@ -70,12 +79,17 @@ static inline void rng_event(oracle_rng *r, int count, double *u)
         }
         return;
     }
-    uint32_t w[4];
-    philox4x32_10(r->pixel, r->sample, r->event, 0u, r->k0, r->k1, w);
-    r->event++;
-    for (int i = 0; i < count; ++i)
-        u[i] = (double)(w[i] >> 8) * (1.0 / 16777216.0);
+    for (int i = 0; i < count; ++i) {
+        if (r->have == 0) {
+            philox4x32_10(r->pixel, r->sample, r->event, 0u, r->k0, r->k1, r->w);
+            r->event++;
+            r->have = 4;
+        }
+        u[i] = (double)(r->w[4 - r->have] >> 8) * (1.0 / 16777216.0);
+        r->have--;
+    }
 }
+static inline void rng_end_run(oracle_rng *r) { r->have = 0; }
 
 /* Row list of a call: rows j = row_begin, row_begin+row_step, ... < row_end. */
 static inline int params_rows(const oracle_params *p)

@@ -56,14 +56,14 @@ static inline vec3 refract(vec3 uv, vec3 n, double etai_over_etat)
 }
 
 /* random_in_range(-1,1) components (:26-35) and random_in_unit_sphere (:37-45):
- * one event = one (x,y,z) try; gen_range(-1.0..=1.0) -> 2u-1. */
+ * one run of (x,y,z) tries, three consecutive words each; gen_range(-1.0..=1.0) -> 2u-1. */
 static vec3 random_in_unit_sphere(oracle_rng *rng)
 {
     for (;;) {
         double u[3];
-        rng_event(rng, 3, u);
+        rng_take(rng, 3, u);
         vec3 p = v3(2.0 * u[0] - 1.0, 2.0 * u[1] - 1.0, 2.0 * u[2] - 1.0);
-        if (length_squared(p) < 1.0) return p;
+        if (length_squared(p) < 1.0) { rng_end_run(rng); return p; }
     }
 }
 static vec3 random_unit_vector(oracle_rng *rng) { return unit_vector(random_in_unit_sphere(rng)); } /* :47-49 */
@@ -160,7 +160,8 @@ static int scatter(const sphere64 *m, const ray *r_in, const hit_record *rec, or
         if (can_refract) {                    /* && short-circuit: draw only if can_refract */
             double u;
             double refl = reflectence(cos_theta, refraction_ratio);
-            rng_event(rng, 1, &u);
+            rng_take(rng, 1, &u);
+            rng_end_run(rng);
             do_refract = refl <= u;
         }
         if (do_refract) direction = refract(unit_direction, rec->normal, refraction_ratio);
@@ -220,15 +221,16 @@ static ray sample_ray(const oracle_camera *cam, const oracle_params *p, int i, i
 {
     rng_init(rng, p->seed, (uint32_t)j * (uint32_t)p->width + (uint32_t)i, (uint32_t)s);
     double e[4];
-    rng_event(rng, 4, e);
+    rng_take(rng, 4, e);                                       /* B_0: one run with the lens tries that follow */
     double u = ((double)i + e[0]) / (double)(p->width - 1);    /* main.rs:131 */
     double v = ((double)j + e[1]) / (double)(p->height - 1);   /* main.rs:132 */
     /* random_in_unit_disk, vec3.rs:59-68: gen_range(-1.0..1.0) -> 2u-1 */
     double lx = 2.0 * e[2] - 1.0, ly = 2.0 * e[3] - 1.0;
     while (!(length_squared(v3(lx, ly, 0.0)) < 1.0)) {
-        rng_event(rng, 2, e);
+        rng_take(rng, 2, e);
         lx = 2.0 * e[0] - 1.0; ly = 2.0 * e[1] - 1.0;
     }
+    rng_end_run(rng);
     return get_ray(cam, u, v, lx, ly);
 }
 

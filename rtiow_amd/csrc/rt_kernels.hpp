@@ -328,12 +328,14 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
             // vec3.rs:59-68: redraw until x*x + y*y < 1.  x = u11(w) = m * 2^-23 with the integer m = (w >> 8) - 2^23, and
             // the f64 sum of squares of such values is EXACT (47 bits), so the reference's f64 comparison is the integer
             // comparison m_x^2 + m_y^2 < 2^46: the loop runs on integers, the accepted pair is converted once.
+            // Block 0 = (u jitter, v jitter, lens x, lens y); every further block holds TWO tries.
             uint32_t wx = w.z, wy = w.w;
             while (!unit_disk_accepts(wx, wy)) {
                 RT_COUNT(2);
                 w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
                 ev++;
                 wx = w.x; wy = w.y;
+                if (!unit_disk_accepts(wx, wy)) { wx = w.z; wy = w.w; }
             }
             const double lx = u11(wx), ly = u11(wy);
             const D3 cam_origin = ld3(P.cam.origin);
@@ -947,15 +949,41 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 U4 w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
                 w_first = w.x;
                 if (kind != RT_KIND_DIALECTRIC) {
-                    ev++;
                     // vec3.rs:37-45: redraw until |p|^2 < 1 -- on the integers behind the three uniforms, where the
-                    // reference's f64 comparison is exact (see unit_sphere_accepts); converted once, after the loop
-                    while (!unit_sphere_accepts(w.x, w.y, w.z)) {
-                        RT_COUNT(6);
-                        w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
-                        ev++;
+                    // reference's f64 comparison is exact (see unit_sphere_accepts); converted once, after the loop.
+                    // The tries of one scatter take consecutive words of consecutive blocks:
+                    // four tries per three blocks.
+                    uint32_t tx = w.x, ty = w.y, tz = w.z, nblk = 1u;
+                    bool ok = unit_sphere_accepts(tx, ty, tz);
+                    if (!ok) {
+                        uint32_t c0 = w.w;                                       // the word left over from the block before
+                        do {
+                            RT_COUNT(6);
+                            U4 b = philox4x32_10(pix_global, (uint32_t)s, ev + nblk, 0u, P.k0, P.k1);
+                            nblk++;
+                            tx = c0; ty = b.x; tz = b.y;                         // try 4m+1
+                            ok = unit_sphere_accepts(tx, ty, tz);
+                            if (!ok) {
+                                const uint32_t c1 = b.z, c2 = b.w;
+                                b = philox4x32_10(pix_global, (uint32_t)s, ev + nblk, 0u, P.k0, P.k1);
+                                nblk++;
+                                tx = c1; ty = c2; tz = b.x;                      // try 4m+2
+                                ok = unit_sphere_accepts(tx, ty, tz);
+                                if (!ok) {
+                                    tx = b.y; ty = b.z; tz = b.w;                // try 4m+3: no new block
+                                    ok = unit_sphere_accepts(tx, ty, tz);
+                                    if (!ok) {
+                                        b = philox4x32_10(pix_global, (uint32_t)s, ev + nblk, 0u, P.k0, P.k1);
+                                        nblk++;
+                                        tx = b.x; ty = b.y; tz = b.z; c0 = b.w;  // try 4m+4 = try 0 of the next three blocks
+                                        ok = unit_sphere_accepts(tx, ty, tz);
+                                    }
+                                }
+                            }
+                        } while (!ok);
                     }
-                    sp = mk(u11(w.x), u11(w.y), u11(w.z));
+                    ev += nblk;
+                    sp = mk(u11(tx), u11(ty), u11(tz));
                 } else {
                     const double2 mD = *reinterpret_cast<const double2 *>(mrec + 6);  // 1/ir, r0(1/ir)
                     const double2 mE = *reinterpret_cast<const double2 *>(mrec + 8);  // r0(ir), -
