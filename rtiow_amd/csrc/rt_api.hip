@@ -55,7 +55,9 @@ struct rt_context {
     uint4 *d_btube = nullptr;      // [tiles/2 + 1][64] MODE 5 (tube filter) B operands
     float *d_rtube = nullptr;      // [tiles/2 + 1][32] MODE 5 per-sphere bounds
     float tube_rho = 1.0f;         // MODE 5 radius floor
-    float box_lo[3] = {1.0f, 1.0f, 1.0f}, box_hi[3] = {-1.0f, -1.0f, -1.0f}, box_scale = 0.0f;   // MODE 5: box of the scanned spheres
+    float boxes[rt::kMaxBoxes][6] = {};   // MODE 5: boxes that hold every scanned sphere (lo xyz, hi xyz)
+    float box_scale = 0.0f;
+    int n_boxes = 0;
 #ifdef RTIOW_CROSSCHECK_MODES
     float *d_bmat = nullptr;       // [tiles][64] MFMA B operand of the filter
     float *d_kpt = nullptr;        // [tiles][16] K' per sphere
@@ -443,24 +445,54 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
         std::vector<char> never(n > 0 ? n : 1, 0);
         for (int e = 0; e < ctx->n_always; ++e) never[ctx->always_idx[e]] = 1;
         ctx->tube_rho = tube_radius_floor(spheres, n, never.data());
-        // the box around every sphere the tables hold (rt_device.hpp, ray_may_reach_box), rounded outwards
-        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int i = 0; i < n; ++i) {
-            if (never[i]) continue;
-            const double r = std::fabs(spheres[i].radius);
-            for (int k = 0; k < 3; ++k) {
-                lo[k] = std::min(lo[k], spheres[i].center[k] - r);
-                hi[k] = std::max(hi[k], spheres[i].center[k] + r);
+        // Bounding boxes of the scanned spheres (rt_device.hpp, ray_may_reach_boxes), rounded outwards: the
+        // (up to 3) spheres more than 3x the median radius of the scanned ones get a box each -- they would
+        // otherwise make the common box as tall as themselves -- and the rest share one.
+        {
+            std::vector<int> idx;
+            for (int i = 0; i < n; ++i) if (!never[i]) idx.push_back(i);
+            std::vector<double> rr;
+            for (int i : idx) rr.push_back(std::fabs(spheres[i].radius));
+            double med = 0.0;
+            if (!rr.empty()) { std::nth_element(rr.begin(), rr.begin() + rr.size() / 2, rr.end()); med = rr[rr.size() / 2]; }
+            std::vector<int> big;
+            for (int i : idx) if (std::fabs(spheres[i].radius) > 3.0 * med) big.push_back(i);
+            std::sort(big.begin(), big.end(), [&](int x, int y) { return std::fabs(spheres[x].radius) > std::fabs(spheres[y].radius); });
+            if (big.size() > (size_t)rt::kMaxBoxes - 1) big.resize(rt::kMaxBoxes - 1);
+            std::vector<char> own(n > 0 ? n : 1, 0);
+            for (int i : big) own[i] = 1;
+            ctx->n_boxes = 0;
+            ctx->box_scale = 0.0f;
+            double scale[3] = {0.0, 0.0, 0.0};
+            auto add_box = [&](const double lo[3], const double hi[3]) {
+                float *bx = ctx->boxes[ctx->n_boxes++];
+                for (int k = 0; k < 3; ++k) {
+                    float fl = (float)lo[k], fh = (float)hi[k];
+                    if ((double)fl > lo[k]) fl = std::nextafterf(fl, -INFINITY);
+                    if ((double)fh < hi[k]) fh = std::nextafterf(fh, INFINITY);
+                    bx[k] = fl; bx[3 + k] = fh;
+                    scale[k] = std::max(scale[k], (double)std::max(std::fabs(fl), std::fabs(fh)));
+                }
+            };
+            for (int i : big) {
+                const double r = std::fabs(spheres[i].radius);
+                const double lo[3] = {spheres[i].center[0] - r, spheres[i].center[1] - r, spheres[i].center[2] - r};
+                const double hi[3] = {spheres[i].center[0] + r, spheres[i].center[1] + r, spheres[i].center[2] + r};
+                add_box(lo, hi);
             }
-        }
-        ctx->box_scale = 0.0f;
-        for (int k = 0; k < 3; ++k) {
-            if (lo[k] > hi[k]) { ctx->box_lo[k] = 1.0f; ctx->box_hi[k] = -1.0f; continue; }     // no scanned sphere
-            float fl = (float)lo[k], fh = (float)hi[k];
-            if ((double)fl > lo[k]) fl = std::nextafterf(fl, -INFINITY);
-            if ((double)fh < hi[k]) fh = std::nextafterf(fh, INFINITY);
-            ctx->box_lo[k] = fl; ctx->box_hi[k] = fh;
-            ctx->box_scale += std::max(std::fabs(fl), std::fabs(fh));
+            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            bool any_rest = false;
+            for (int i : idx) {
+                if (own[i]) continue;
+                any_rest = true;
+                const double r = std::fabs(spheres[i].radius);
+                for (int k = 0; k < 3; ++k) {
+                    lo[k] = std::min(lo[k], spheres[i].center[k] - r);
+                    hi[k] = std::max(hi[k], spheres[i].center[k] + r);
+                }
+            }
+            if (any_rest) add_box(lo, hi);
+            ctx->box_scale = (float)(scale[0] + scale[1] + scale[2]) * 1.0001f;
         }
         for (size_t t = 0; t < ttc; ++t) {
             const rt_sphere *col[32];
@@ -608,11 +640,9 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.bmat16 = ctx->d_bmat16; kp.kpt16 = ctx->d_kpt16; kp.bmatL = ctx->d_bmatL;
 #endif
     kp.btube = ctx->d_btube; kp.rtube = ctx->d_rtube; kp.tube_rho = ctx->tube_rho;
-    for (int k = 0; k < 3; ++k) { kp.box_lo[k] = ctx->box_lo[k]; kp.box_hi[k] = ctx->box_hi[k]; }
+    memcpy(kp.boxes, ctx->boxes, sizeof(kp.boxes));
     kp.box_scale = ctx->box_scale;
-    if (env_int("RTIOW_NO_BOX_CULL", 0)) {          // diagnostic A/B: a box no ray can miss
-        for (int k = 0; k < 3; ++k) { kp.box_lo[k] = -1e30f; kp.box_hi[k] = 1e30f; }
-    }
+    kp.n_boxes = env_int("RTIOW_NO_BOX_CULL", 0) ? -1 : ctx->n_boxes;      // (diagnostic A/B: -1 = never cull)
     kp.n_always = ctx->n_always;
     for (int e = 0; e < 8; ++e) kp.always_idx[e] = ctx->always_idx[e];
     kp.fix = (unsigned long long *)d_fix;

@@ -350,35 +350,38 @@ constexpr float kTubeBasisErr = 64.0f * kUnitRoundoff;
 constexpr float kTubeCenterErr = 640.0f * kUnitRoundoff;
 constexpr float kTubeOriginErr = 128.0f * kUnitRoundoff;
 
-// Can the ray o + t d, t > 0, come within reach of the axis-aligned box [lo, hi] that holds every scanned sphere
-// (host: rounded outwards)?  Slab test in f32, biased to answer "yes":
+// Can the ray o + t d, t > 0, come within reach of one of n axis-aligned boxes (box[k] = lo xyz, hi xyz; together
+// they hold every scanned sphere; host: rounded outwards)?  Slab tests in f32, biased to answer "yes":
 //   * o and d are rounded to f32 (6e-8 relative each): the line they define stays within 6e-8 (|o| + L) of the true
-//     one at distance L, and the box can only matter for L <= |o| + its own size, so it is grown by
+//     one at distance L, and a box can only matter for L <= |o| + the scene's size, so every box is grown by
 //     e = 1e-6 (|o|_1 + scale) on every side;
 //   * v_rcp_f32 and the products put <= 3e-7 relative error on each slab parameter: the interval test keeps a
 //     ray unless the exit parameter lies below 0.9999 of the entry parameter;
 //   * a direction component of magnitude < 1e-30, a non-finite value or |o|, |d| beyond 1e15: always "yes"
 //     (a NaN anywhere makes the final comparison false, which also answers "yes").
-// An empty box (lo > hi: no scanned sphere) answers "no" for every ordinary ray.
-__device__ __forceinline__ bool ray_may_reach_box(D3 o, D3 d, const float (&lo)[3], const float (&hi)[3], float scale)
+constexpr int kMaxBoxes = 4;
+__device__ __forceinline__ bool ray_may_reach_boxes(D3 o, D3 d, const float (&box)[kMaxBoxes][6], int n, float scale)
 {
     const float of[3] = {(float)o.x, (float)o.y, (float)o.z};
     const float df[3] = {(float)d.x, (float)d.y, (float)d.z};
     const float o1 = __builtin_fabsf(of[0]) + __builtin_fabsf(of[1]) + __builtin_fabsf(of[2]);
     const float e = 1e-6f * (o1 + scale);
-    float t_in = 0.0f, t_out = __builtin_inff();
-    float dmin = __builtin_inff(), dmax = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float inv = __builtin_amdgcn_rcpf(df[k]);
-        const float a = ((lo[k] - e) - of[k]) * inv, b = ((hi[k] + e) - of[k]) * inv;
-        t_in = __builtin_fmaxf(t_in, __builtin_fminf(a, b));
-        t_out = __builtin_fminf(t_out, __builtin_fmaxf(a, b));
-        dmin = __builtin_fminf(dmin, __builtin_fabsf(df[k]));
-        dmax = __builtin_fmaxf(dmax, __builtin_fabsf(df[k]));
-    }
+    const float inv[3] = {__builtin_amdgcn_rcpf(df[0]), __builtin_amdgcn_rcpf(df[1]), __builtin_amdgcn_rcpf(df[2])};
+    const float dmin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(df[0]), __builtin_fabsf(df[1])), __builtin_fabsf(df[2]));
+    const float dmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(df[0]), __builtin_fabsf(df[1])), __builtin_fabsf(df[2]));
     const bool sane = dmin > 1e-30f && dmax < 1e15f && o1 < 1e15f;
-    return !sane || !(t_out < t_in * 0.9999f);
+    bool any = !sane;
+    for (int k = 0; k < n; ++k) {                       // n is wave-uniform
+        float t_in = 0.0f, t_out = __builtin_inff();
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float t0 = ((box[k][a] - e) - of[a]) * inv[a], t1 = ((box[k][3 + a] + e) - of[a]) * inv[a];
+            t_in = __builtin_fmaxf(t_in, __builtin_fminf(t0, t1));
+            t_out = __builtin_fminf(t_out, __builtin_fmaxf(t0, t1));
+        }
+        any = any || !(t_out < t_in * 0.9999f);
+    }
+    return any;
 }
 
 struct TubeRay {

@@ -67,10 +67,12 @@ struct KParams {
     const uint4 *btube;        // [tiles/2 + 1][64] MODE 5 B operands: 32 spheres x 16 K-slots (rt_device.hpp)
     const float *rtube;        // [tiles/2 + 1][32] MODE 5 per-sphere bound max(R, rho); negative: never kept
     float tube_rho;            // MODE 5 radius floor
-    // MODE 5: axis-aligned box around every sphere of the filter tables (the always-exact ones excluded), rounded
-    // outwards; a ray that cannot reach it skips the scan (a wave whose rays all skip it skips the tile loop).
-    // box_lo > box_hi: no such sphere.  box_scale = sum over axes of max(|lo|, |hi|).
-    float box_lo[3], box_hi[3], box_scale;
+    // MODE 5: up to kMaxBoxes axis-aligned boxes (rounded outwards) that together hold every sphere of the filter
+    // tables (the always-exact ones excluded): one per sphere that is much larger than the rest, one around the rest.
+    // A NEW CAMERA RAY that can reach none of them has nothing to scan (rt_device.hpp, ray_may_reach_boxes).
+    float boxes[4][6];         // [k] = lo x, y, z, hi x, y, z
+    float box_scale;           // sum over axes of the largest |coordinate| of any box
+    int32_t n_boxes;
     int32_t n_tiles;
     int32_t n_always;          // spheres that skip the filter and are always tested exactly
     int32_t always_idx[8];
@@ -586,11 +588,14 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
             if constexpr (TUBE) {
                 if (alive)
                     for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e]); }
-                // A ray that cannot reach the box around the scanned spheres (a camera ray into the sky, a bounce
-                // that leaves the scene) has nothing to scan; a wave in which NO ray can -- the waves working on
-                // sky pixels, where every lane starts a new camera ray in every pass -- skips operands, tile
-                // loop and pool altogether.  Conservative like the filter itself: never changes a result.
-                const bool scan = alive && ray_may_reach_box(o, d, P.box_lo, P.box_hi, P.box_scale);
+                // Camera rays into the sky: in the image rows above the scene every lane of a wave starts a new
+                // camera ray in every pass, and none of them can reach a sphere.  When ALL rays of a pass are new
+                // camera rays (one ballot; practically never true elsewhere) they are tested against the scene's
+                // bounding boxes, and a wave in which no ray reaches one skips operands, tile loop and pool (16-ray
+                // groups without such a ray skip their MFMAs).  Conservative like the filter: never changes a result.
+                bool scan = alive;
+                if (__ballot(alive && !fresh) == 0ull)      // (wave-uniform) every ray of this pass is a new camera ray
+                    scan = alive && (P.n_boxes < 0 || ray_may_reach_boxes(o, d, P.boxes, P.n_boxes, P.box_scale));
                 const unsigned long long scan_mask = __ballot(scan);
                 if (scan_mask != 0ull) {
                 const TubeRay T = scan ? make_tube(o, d, P.tube_rho) : no_tube_ray();
@@ -663,6 +668,9 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                     }
                 };
                 RT_STAMP(5);
+                // waves in the tile loop issue ahead of their SIMD partners: the matrix pipe is fed sooner and the other
+                // waves' vector work fills the time the MFMAs take (measured: -1.4 % on configs[1])
+                __builtin_amdgcn_s_setprio(1);
                 for (int seg0 = 0; seg0 < nt; seg0 += kSegTiles) {
                     const int seg_n = min(kSegTiles, nt - seg0);
                     const int nwords = seg_n >> 1;                  // one bitmap word per 32-sphere tile
@@ -718,7 +726,9 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                     }
                     __builtin_amdgcn_wave_barrier();
                     RT_STAMP(6);
+                    __builtin_amdgcn_s_setprio(0);
                     enumerate(seg0);
+                    if (seg0 + kSegTiles < nt) __builtin_amdgcn_s_setprio(1);
                 }
                 finish_pool();
                 }   // scan_mask != 0
