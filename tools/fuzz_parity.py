@@ -30,6 +30,8 @@ for case in range(cases):
         w.push(rt.Sphere(c, rad, m))
     flat = w.flatten()
     W, H, spp = int(rng.integers(8, 64)), int(rng.integers(6, 48)), int(rng.integers(1, 5))
+    if rng.random() < 0.3:          # launches of >= 37 spp keep their work blocks' sums in LDS (a different write path)
+        W, H, spp = int(rng.integers(6, 28)), int(rng.integers(5, 20)), int(rng.integers(37, 90))
     lf = rng.uniform(-spread, spread, 3); lf[1] = abs(lf[1]) * 0.3 + 0.3 * spread / 10
     la = rng.uniform(-spread, spread, 3) * 0.3
     cam = rt.Camera(lf, la, rt.Vec3(0, 1, 0), float(rng.uniform(5, 120)), W / H, float(rng.uniform(0.0, 0.5)) * spread / 10,

@@ -4,7 +4,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa
 from rtiow_amd import _ffi
-_ffi.LIB_PATH = os.environ.get("RTIOW_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtiow_hip_stamps.so")
+_ffi.LIB_PATH = os.environ.get("RTIOW_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib_stamps.so")   # tools/build_diag_libs.sh
 import rtiow_amd as rt
 names = ["(a) fetch item", "(b) camera ray", "(d) exact tests (list)", "-", "(e) shade+accumulate", "(d) operands + always-exact", "(d) matrix tile loop", "(d) bitmap -> list"]
 for mode in [int(x) for x in os.environ.get("MODES", "4").split(",")]:
