@@ -1,0 +1,36 @@
+"""bench.py's host-side logic (no GPU): the self-launch command for --gpus N, and the replayed-counter file."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_self_launch_command_is_a_torchrun_child_on_loopback():
+    cmd = bench.launch_command(8, 29555, ["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+
+
+def test_help_needs_neither_torch_nor_a_gpu():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "--rehearse-on-one-gpu" in r.stdout
+
+
+def test_pmc_replay_entries_name_their_source_and_kernel():
+    path = os.path.join(ROOT, "profiles", "pmc_replay.json")
+    entries = json.load(open(path))["entries"]
+    assert any(e["config"] == [1200, 675, 500, 1] for e in entries)      # the bench default
+    for e in entries:
+        assert "NOT measured in this bench run" in e["source"] and e["source"].startswith("profiles/")
+        assert len(e["kernel_source_sha"]) == 16 and e["valu_insts_per_launch"] > 0 and 0 < e["valu_busy"] <= 1.5
+        assert os.path.exists(os.path.join(ROOT, e["source"].split(":")[0]))
+    sha = bench.kernel_source_sha()
+    if not any(e["kernel_source_sha"] == sha for e in entries):
+        print(f"note: profiles/pmc_replay.json was taken on other kernel sources than {sha}: bench.py will null the counters")

@@ -283,3 +283,21 @@ def test_zero_radius_is_rejected(book1_flat):
             fresh.render(rt.book1_camera(8, 8), rt.make_params(8, 8, 1))
     finally:
         fresh.close()
+
+
+@pytest.mark.parametrize("w,h,spp,tile", [(40000, 2, 3, 1), (2, 40000, 3, 33000), (35000, 3, 40, 2), (3, 1000, 300, 7)])
+def test_extreme_aspect_ratios_and_tile_sizes(renderer, oracle_mod, book1_flat, w, h, spp, tile):
+    """Item -> (pixel, sample, row, column) runs on multiply-high with host-made reciprocals (udiv_small): widths and
+    tile heights beyond 2^15 take the 'quotient is 0 or 1' branch, 3-pixel rows carry a block over many rows."""
+    renderer.upload_scene(book1_flat)
+    cam = rt.book1_camera(w, h)
+    sm, fix, st = renderer.render(cam, rt.make_params(w, h, spp, seed=3, tile_rows=tile))
+    fb, sb, stb = oracle_mod.render_b(oracle_mod.camera_from_host(cam), book1_flat, oracle_mod.make_params(w, h, spp, seed=3))
+    assert np.array_equal(fix, fb) and st["rays_traced"] == stb["rays_traced"] and st["samples"] == w * h * spp
+    if tile < h:                                            # and as two shards
+        full = np.zeros_like(fix)
+        for k in range(2):
+            p = rt.make_params(w, h, spp, seed=3, tile_rows=tile, shard_index=k, shard_count=2)
+            _, part, _ = renderer.render(cam, p)
+            full[rt.shard_row_indices(p)] = part
+        assert np.array_equal(full, fb)
