@@ -51,6 +51,11 @@ print("wrote", DST)
 #  (iii) silhouettes above the horizon: leftmost / rightmost non-sky pixel per row (Lambertian sphere at
 #        (-4,1,0), Metal sphere at (4,1,0)), topmost non-sky pixel per column (all three).
 #  (iv)  the mean colour of a patch of the Lambertian sphere (albedo (0.4,0.2,0.1)) that faces the sky.
+#  (v)   the mean colour of a patch in the LOWER half of the Dialectric sphere at (0,1,0), ir 1.5: refraction turns
+#        the image upside down, so that half shows the sky -- camera ray refracted in, refracted out
+#        (materials.rs:76-105, vec3.rs:120-125), minus the few per cent Schlick sends elsewhere.  The patch mean does
+#        not depend on the small spheres (three scene seeds agree within 0.3) but moves by 1.1 for ir 1.45 and 2.1
+#        for ir 1.6.
 # "non-sky" = differs from the sky the camera would see there by more than 6 in some channel; the sky
 # reference is Oracle A on an EMPTY scene (this script is test infrastructure and may load the oracle).
 import sys
@@ -121,7 +126,10 @@ for y in range(60, 180, 10):
 top = {str(x): int(Y0 + np.argmax(nonsky[:, x])) for x in range(460, 1001, 20)}
 patch = {"x0": 380, "x1": 440, "y0": 110, "y1": 170}
 patch["mean_rgb"] = [float(c) for c in im[patch["y0"]:patch["y1"], patch["x0"]:patch["x1"], :3].reshape(-1, 3).mean(0)]
+glass = {"x0": 470, "x1": 540, "y0": 260, "y1": 320}
+glass["mean_rgb"] = [float(c) for c in im[glass["y0"]:glass["y1"], glass["x0"]:glass["x1"], :3].reshape(-1, 3).mean(0)]
 json.dump({"source": "rtiow_part1_final.png", "width": W, "height": H, "nonsky_threshold": 6, "rows_scanned": [Y0, Y1],
+           "dialectric_patch": glass,
            "metal_cap_rows": cap, "horizon_first_nonsky_row": horizon, "silhouette_left_right": left_right,
            "silhouette_top": top, "lambertian_patch": patch}, open(DST2, "w"))
 print("wrote", DST2)

@@ -58,3 +58,13 @@ def check_lambertian_patch(fx, rows_rgb):
     p, y0 = fx["lambertian_patch"], fx["rows_scanned"][0]
     got = rows_rgb[p["y0"] - y0:p["y1"] - y0, p["x0"]:p["x1"]].reshape(-1, 3).astype(float).mean(0)
     assert np.abs(got - np.array(p["mean_rgb"])).max() <= 1.5, (got, p["mean_rgb"])
+
+
+def check_dialectric_patch(fx, rows_rgb_of):
+    """rows_rgb_of(y0, y1) -> [y1-y0, W, 3].  Mean colour of a patch in the lower half of the Dialectric sphere
+    (0,1,0), ir 1.5, which shows the refracted (upside-down) sky: pins refract(), the front/back ratio, total
+    internal reflection and the Schlick mix of materials.rs:76-105 statistically -- the mean moves by 1.1 for
+    ir 1.45 and by 2.1 for ir 1.6, and by < 0.3 between differently seeded small spheres."""
+    p = fx["dialectric_patch"]
+    got = rows_rgb_of(p["y0"], p["y1"])[:, p["x0"]:p["x1"]].reshape(-1, 3).astype(float).mean(0)
+    assert np.abs(got - np.array(p["mean_rgb"])).max() <= 0.8, (got, p["mean_rgb"])

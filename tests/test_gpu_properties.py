@@ -158,7 +158,8 @@ def test_gpu_reproduces_what_the_reference_png_holds_about_the_big_spheres(rende
     """tests/png_pins.py on the GPU render (1200x800, 3:2, 48 spp): the sky mirrored in the fuzz-0 Metal sphere
     within 1 of the PNG, the silhouettes of the three hard-coded spheres and the ground's horizon where the PNG
     has them, the mean colour of the Lambertian sphere's sky-facing patch -- the reference's own artefact
-    pinning Sphere::hit, HitRecord::new, Metal::scatter/reflect and Lambertian::scatter on the device."""
+    pinning Sphere::hit, HitRecord::new, Metal::scatter/reflect, Lambertian::scatter and -- through the refracted sky
+    in the lower half of the glass sphere -- Dialectric::scatter on the device."""
     import png_pins
     fx = png_pins.fixture()
     w, h, spp = 1200, 800, 48
@@ -173,6 +174,7 @@ def test_gpu_reproduces_what_the_reference_png_holds_about_the_big_spheres(rende
     png_pins.check_metal_cap(fx, lambda y: rgb[y])
     png_pins.check_silhouettes_and_horizon(fx, png_pins.nonsky_mask(fx, rgb[y0:y1], sky[y0:y1]))
     png_pins.check_lambertian_patch(fx, rgb[y0:y1])
+    png_pins.check_dialectric_patch(fx, lambda a, b: rgb[a:b])
 
 
 def test_all_scan_filters_give_the_same_bits(book1_flat, cfg2):

@@ -1,8 +1,8 @@
 """Oracle A against what the reference's committed render holds about the three hard-coded big spheres
 (tests/png_pins.py): with test_oracle_sky_png.py this pins, on the reference's own artefact, Sphere::hit,
 HitRecord::new, Metal::scatter + reflect, the Lambertian scatter distribution and the sphere/camera geometry --
-SURVEY.md section 8 rows a5-a9 (the Dialectric's refraction, row a10, shows in the PNG only mixed with the
-unknown small spheres behind it: its silhouette is pinned, its shading stays pinned by analytic KATs only)."""
+SURVEY.md section 8 rows a5-a10 (the Dialectric through the mean of the refracted sky in its lower half; what the
+PNG cannot pin is the equal-t tie rule and t_min strictness: analytic known answers only)."""
 import numpy as np
 import pytest
 
@@ -45,6 +45,15 @@ def test_silhouettes_and_horizon_as_in_the_png(fx, scanned):
 
 def test_lambertian_patch_mean_as_in_the_png(fx, scanned):
     png_pins.check_lambertian_patch(fx, scanned[0])
+
+
+def test_glass_sphere_shows_the_refracted_sky_as_in_the_png(oracle_mod, cam, book1_flat, fx):
+    png_pins.check_dialectric_patch(fx, lambda y0, y1: render_rows(oracle_mod, cam, book1_flat, y0, y1, 64))
+    other = book1_flat.copy()                              # ir 1.6 instead of 1.5 must not pass
+    k = int(np.nonzero((other["center"] == (0.0, 1.0, 0.0)).all(axis=1))[0][0])
+    other["param"][k] = 1.6
+    with pytest.raises(AssertionError):
+        png_pins.check_dialectric_patch(fx, lambda y0, y1: render_rows(oracle_mod, cam, other, y0, y1, 64))
 
 
 def test_the_checks_can_fail(oracle_mod, cam, book1_flat, fx):
