@@ -205,14 +205,17 @@ int rt_filter_lifted_device(rt_context *ctx, const double *o, const double *d, c
 #endif /* RTIOW_CROSSCHECK_MODES */
 /* One tile of the tube filter, the shipped scan mode: o, d: [64][3] f64 rays; spheres32: 32 spheres
  * (one tile of columns, built exactly as rt_upload_scene builds them, radius floor included);
- * out_h: [64][32][2] the two per-direction values whose magnitudes the kernel compares with
- * out_bound[32]; out_rows: [64][9] = (lambda u_1, lambda u_2, t_1, t_2, 1 if the ray is inside the
- * analysed range); out_rho: the radius floor chosen for these 32 spheres. */
+ * out_h: [64][32][2] the two per-direction values H_k as the matrix pipe returns them, in units of HALF the
+ * sphere's bound: the kernel keeps a (ray, sphere) pair iff |H_1| < 2 and |H_2| < 2 (it tests one bit of each);
+ * out_bound[32]: the bound max(R, rho) each column was scaled with (sigma = 2 (1 - 2^-6) / bound, rounded down
+ * to a bf16, is the value in K-slots 12..14 of the column); out_rows: [64][9] = (lambda u_1, lambda u_2, t_1, t_2,
+ * 1 if the ray is inside the analysed range); out_rho: the radius floor chosen for these 32 spheres. */
 int rt_filter_tube_device(rt_context *ctx, const double *o, const double *d, const rt_sphere *spheres32,
                           float *out_h, float *out_rows, float *out_bound, float *out_rho);
 /* The host half of the same tile, no device needed: the 32 columns exactly as rt_upload_scene lays them
  * out.  out_words: [64][4] u32 = the B operand of lane l (column l&31, K-slots 8(l>>5)..+7, two bf16 per
- * word, low half first); out_bound: [32]; out_rho: the radius floor. */
+ * word, low half first): slots 0..11 two bf16 pieces of sigma * centre per coordinate as (y1, y2, y1, y2),
+ * slots 12..14 sigma, slot 15 zero (4.0 in a column no ray may keep); out_bound: [32]; out_rho: the radius floor. */
 int rt_tube_tile_host(const rt_sphere *spheres32, uint32_t *out_words, float *out_bound, float *out_rho);
 int rt_philox_device(rt_context *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

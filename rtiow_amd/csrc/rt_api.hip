@@ -53,7 +53,6 @@ struct rt_context {
     double *d_geo = nullptr;       // [n][4] exact geometry
     double *d_mat = nullptr;       // [n][kMatStride] exact materials
     uint4 *d_btube = nullptr;      // [tiles/2 + 1][64] MODE 5 (tube filter) B operands
-    float *d_rtube = nullptr;      // [tiles/2 + 1][32] MODE 5 per-sphere bounds
     float tube_rho = 1.0f;         // MODE 5 radius floor
     float boxes[rt::kMaxBoxes][6] = {};   // MODE 5: boxes that hold every scanned sphere (lo xyz, hi xyz)
     float box_scale = 0.0f;
@@ -231,8 +230,18 @@ float tube_bound(const rt_sphere &s, float rho)
     if ((double)f < R) f = std::nextafterf(f, INFINITY);
     return f > rho ? f : rho;
 }
-// one tile of 32 columns: B operands [64] (lane l = column l&31, K-slots 8(l>>5)..+7) and bounds [32].
-// `s[c] == nullptr`: a column no ray keeps (padding, always-exact list).
+// sigma of one sphere: 2 (1 - 2^-6) / bound, rounded DOWN to a bf16 (rt_device.hpp: "kept" <=> |H| < 2);
+// 0 for a sphere outside the analysed range (bound = +inf): H = 0, always kept.  Returns the bf16 bit pattern.
+uint32_t tube_sigma_bits(float bound)
+{
+    if (!(bound < INFINITY)) return 0u;
+    const float f = (float)(2.0 * (1.0 - 1.0 / 64.0) / (double)bound);
+    uint32_t u; memcpy(&u, &f, 4);
+    return u >> 16;                                    // truncation = rounding down (sigma > 0)
+}
+// one tile of 32 columns: B operands [64] (lane l = column l&31, K-slots 8(l>>5)..+7) and, for the tests, the
+// bounds [32] the columns were scaled with.  `s[c] == nullptr`: a column no ray keeps (padding, always-exact list):
+// all zero but for K-slot 15, where 4 meets the 1 every ray carries there.
 void tube_tile(const rt_sphere *const s[32], float rho, uint4 out_b[64], float out_r[32])
 {
     for (int c = 0; c < 32; ++c) {
@@ -240,10 +249,12 @@ void tube_tile(const rt_sphere *const s[32], float rho, uint4 out_b[64], float o
         out_r[c] = -1.0f;
         if (s[c]) {
             out_r[c] = tube_bound(*s[c], rho);
-            if (out_r[c] < INFINITY) {                 // (always-kept columns keep c = 0: h = t, finite)
+            const uint32_t sg = tube_sigma_bits(out_r[c]);
+            uint32_t sgu = sg << 16; float sigma; memcpy(&sigma, &sgu, 4);
+            if (sg != 0u) {                            // (always-kept columns keep sigma = 0, c = 0: H = 0)
                 for (int i = 0; i < 3; ++i) {
-                    // two bf16 pieces of the f64 centre: |c - (y1 + y2)| <= 2^-16 |c|
-                    const double ci = s[c]->center[i];
+                    // two bf16 pieces of sigma * (the f64 centre): |sigma c - (y1 + y2)| <= 2^-16 |sigma c|
+                    const double ci = s[c]->center[i] * (double)sigma;
                     const uint32_t y1 = host_bf16_rne((float)ci);
                     uint32_t u1 = y1 << 16; float f1; memcpy(&f1, &u1, 4);
                     const uint32_t y2 = host_bf16_rne((float)(ci - (double)f1));
@@ -251,9 +262,11 @@ void tube_tile(const rt_sphere *const s[32], float rho, uint4 out_b[64], float o
                     w[2 * i + 1] = y1 | (y2 << 16);
                 }
             }
+            w[6] = sg | (sg << 16);                    // sigma against the three exact pieces of t
+            w[7] = sg;
+        } else {
+            w[7] = 0x4080u << 16;                      // K-slot 15: 4.0 -> H = 4 for every ray: never kept
         }
-        w[6] = rt::kBf16One | (rt::kBf16One << 16);
-        w[7] = rt::kBf16One;
         out_b[c] = make_uint4(w[0], w[1], w[2], w[3]);
         out_b[32 + c] = make_uint4(w[4], w[5], w[6], w[7]);
     }
@@ -263,8 +276,8 @@ void tube_tile(const rt_sphere *const s[32], float rho, uint4 out_b[64], float o
 void free_scene(rt_context *ctx)
 {
     (void)hipFree(ctx->d_filt); (void)hipFree(ctx->d_geo); (void)hipFree(ctx->d_mat);
-    (void)hipFree(ctx->d_btube); (void)hipFree(ctx->d_rtube);
-    ctx->d_filt = nullptr; ctx->d_geo = ctx->d_mat = nullptr; ctx->d_btube = nullptr; ctx->d_rtube = nullptr;
+    (void)hipFree(ctx->d_btube);
+    ctx->d_filt = nullptr; ctx->d_geo = ctx->d_mat = nullptr; ctx->d_btube = nullptr;
 #ifdef RTIOW_CROSSCHECK_MODES
     (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt); (void)hipFree(ctx->d_bmat16); (void)hipFree(ctx->d_kpt16);
     (void)hipFree(ctx->d_bmatL);
@@ -503,7 +516,6 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
             tube_tile(col, ctx->tube_rho, &btube[t * 64], &rtube[t * 32]);
         }
         if (!rc) rc = upload_table(&ctx->d_btube, btube.data(), btube.size());
-        if (!rc) rc = upload_table(&ctx->d_rtube, rtube.data(), rtube.size());
     }
     // filter records of the f32 evaluation schemes (mode 1, and the sources of the mode 2/3 tables):
     // centre rounded to f32 + K'
@@ -639,7 +651,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.bmat = ctx->d_bmat; kp.kpt = ctx->d_kpt;
     kp.bmat16 = ctx->d_bmat16; kp.kpt16 = ctx->d_kpt16; kp.bmatL = ctx->d_bmatL;
 #endif
-    kp.btube = ctx->d_btube; kp.rtube = ctx->d_rtube; kp.tube_rho = ctx->tube_rho;
+    kp.btube = ctx->d_btube; kp.tube_rho = ctx->tube_rho;
     memcpy(kp.boxes, ctx->boxes, sizeof(kp.boxes));
     kp.box_scale = ctx->box_scale;
     kp.n_boxes = env_int("RTIOW_NO_BOX_CULL", 0) ? -1 : ctx->n_boxes;      // (diagnostic A/B: -1 = never cull)

@@ -336,9 +336,9 @@ __device__ __forceinline__ void lifted_stage_operands(uint4 *stage, int lane, co
 // three pieces and still carry a slack of 6e-5 (|o|^2+|c|^2)).  Per (ray, direction) row and
 // per-sphere column the 16 K-slots of one v_mfma_f32_32x32x16_bf16 are
 //
-//   slots 4i .. 4i+3 (i = x,y,z):  A (x1,x1,x2,x2)  B (y1,y2,y1,y2)   = (x1+x2)(y1+y2)
-//   slots 12,13,14:                A (t1,t2,t3)     B (1,1,1)         t = -(u_k.o), split exactly
-//   slot 15:                       zero
+//   slots 4i .. 4i+3 (i = x,y,z):  A (x1,x1,x2,x2)  B (y1,y2,y1,y2)   = (x1+x2)(y1+y2),  y = sigma c_i
+//   slots 12,13,14:                A (t1,t2,t3)     B (sigma x 3)     t = -(u_k.o), split exactly; sigma a bf16
+//   slot 15:                       A 1              B 0 (4 in a column that is never kept)
 //
 // and one instruction evaluates 16 rays x 2 directions against 32 spheres.  Soundness:
 // with the basis errors (|u_k.d^| <= 64u, ||u_k|-1| <= 64u, measured <= 8u), the operand truncation
@@ -346,6 +346,14 @@ __device__ __forceinline__ void lifted_stage_operands(uint4 *stage, int lane, co
 //     hit  =>  |h_k| <= R + e,   R = r (1+64u) + 640u |c|   (per sphere),   e = 128u |o|   (per ray).
 // The per-ray part is folded into the rows: they are scaled by lambda = rho / (rho + e), which makes
 // lambda |h_k| <= max(R, rho) for every sphere (rho: a per-scene radius floor chosen on the host).
+// The host folds each sphere's bound into its column: the column holds sigma c and sigma instead of c and 1, with
+// sigma = 2 (1 - 2^-6) / max(R, rho) rounded DOWN to a bf16, so that
+//     hit  =>  |H_k| = sigma lambda |h_k| <= 2 (1 - 2^-6) < 2 = kTubeKeepBelow,
+// and "kept" is a test of ONE BIT of the f32 pattern (biased exponent < 128).  Every error term of the budget above is
+// relative to |c| or |o| and scales with sigma like h itself; the t slots multiply the exact pieces of t by the exact
+// bf16 sigma; 2^-6 covers the rounding of the f32 result next to 2.  K-slot 15 carries 1 (A side) x 0 or 4 (B side):
+// a column that must never be kept (padding, spheres on the always-exact list) is all zero but for that 4.
+constexpr float kTubeKeepBelow = 2.0f;
 constexpr float kTubeBasisErr = 64.0f * kUnitRoundoff;
 constexpr float kTubeCenterErr = 640.0f * kUnitRoundoff;
 constexpr float kTubeOriginErr = 128.0f * kUnitRoundoff;
@@ -446,7 +454,7 @@ __device__ __forceinline__ void tube_a_words(const TubeRay &T, uint32_t (&w)[2][
         }
         const Bf3 t = split_bf16x3_hw(T.t[k]);
         w[k][6] = t.p1 | (t.p2 << 16);
-        w[k][7] = t.p3;
+        w[k][7] = t.p3 | (kBf16One << 16);          // slot 15: 1 (against 0, or 4 in a never-kept column)
     }
 }
 

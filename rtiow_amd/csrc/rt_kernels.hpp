@@ -64,8 +64,7 @@ struct KParams {
     const float *kpt16;        // [tiles][16] K' for the bf16x3 form (larger KU)
     const uint4 *bmatL;        // [tiles][2][64] MODE 4 B operands: the 64 K-slots of the lifted form (rt_device.hpp)
 #endif
-    const uint4 *btube;        // [tiles/2 + 1][64] MODE 5 B operands: 32 spheres x 16 K-slots (rt_device.hpp)
-    const float *rtube;        // [tiles/2 + 1][32] MODE 5 per-sphere bound max(R, rho); negative: never kept
+    const uint4 *btube;        // [tiles/2 + 1][64] MODE 5 B operands: 32 spheres x 16 K-slots, each column scaled by 2 / its bound (rt_device.hpp)
     float tube_rho;            // MODE 5 radius floor
     // MODE 5: up to kMaxBoxes axis-aligned boxes (rounded outwards) that together hold every sphere of the filter
     // tables (the always-exact ones excluded): one per sphere that is much larger than the rest, one around the rest.
@@ -611,40 +610,33 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 const int ntt = nt >> 1;                    // tiles of 32 spheres; the tables hold ntt + 1
                 const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<uint4 *>(P.btube), 0, (ntt + 1) * 1024, 0x00020000);
-                const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float *>(P.rtube), 0, (ntt + 1) * 128, 0x00020000);
-                const int voff = lane * 16, roff = (lane & 31) * 4;
+                const int voff = lane * 16;
                 auto load_b = [&](int t32) -> bf16x8 {
                     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, voff, t32 * 1024, 0));
-                };
-                auto load_r = [&](int t32) -> float {
-                    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, roff, t32 * 128, 0));
                 };
                 const int col32 = lane & 31, hh = lane >> 5;
                 const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 // which 16-ray groups hold at least one ray to scan (wave-uniform)
                 const unsigned groups = ((scan_mask & 0xFFFFull) ? 1u : 0u) | ((scan_mask & 0xFFFF0000ull) ? 2u : 0u) |
                                         ((scan_mask & 0xFFFF00000000ull) ? 4u : 0u) | ((scan_mask >> 48) ? 8u : 0u);
-                // results of one MFMA: acc[8bb + j] / acc[8bb + 4 + j] are h_1 / h_2 of ray 16G + 8bb + 4hh + j
-                // against sphere 32 t + col32; kept iff max(|h_1|, |h_2|) <= bound
-                auto look_tube = [&](int G, const f32x16 &acc, float bound, int wrel) {
-                    // max(|h_1|, |h_2|) in ONE instruction each (source modifiers take the magnitudes); written
-                    // as asm because fmaxf() would first canonicalise both inputs.  The compiler does not see
-                    // into asm, so one ordinary instruction reads the result first (`tok`): the matrix-pipe ->
-                    // VALU wait states are inserted in front of THAT read, and every asm statement is ordered
-                    // behind it.  The results are non-negative floats, which order like integers (v_min3_i32).
-                    int m[2][4];
-                    const int tok = __float_as_int(acc[0]) & 0x7FFFFFFF;
+                // results of one MFMA: acc[8bb + j] / acc[8bb + 4 + j] are H_1 / H_2 of ray 16G + 8bb + 4hh + j against
+                // sphere 32 t + col32, in units of half the sphere's bound (the host scales every column): the pair is
+                // kept iff |H_1| < 2 and |H_2| < 2, i.e. iff bit 30 of BOTH f32 patterns is clear (biased exponent
+                // < 128; infinities and NaNs have it set).  So the look is bit logic: X = AND over the lane's 8 rays of
+                // (H_1 | H_2) -- one v_or_b32 and seven v_bitop3_b32 (a & (b | c)) -- has bit 30 clear iff some ray
+                // keeps this sphere, and ONE compare |X| < 2.0 reads that bit.  9 vector instructions of 2.7-4.9 SIMD
+                // cycles where max/min-trees took 14 of 4.3-5.4 (tools/valu_cost_table.hip: v_max/v_min* cost 4.3-5.4
+                // cycles at four waves per SIMD, v_or/v_bitop3 2.7-3.1): 58 instead of 81 cycles per MFMA + look.
+                auto keeps = [](uint32_t x) -> bool { return __builtin_fabsf(__uint_as_float(x)) < kTubeKeepBelow; };
+                auto look_tube = [&](int G, const f32x16 &acc, int wrel) {
+                    uint32_t X = __float_as_uint(acc[0]) | __float_as_uint(acc[4]);
 #pragma unroll
                     for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(m[bb][j]) : "v"(acc[8 * bb + j]), "v"(acc[8 * bb + 4 + j]), "v"(tok));
-                    const int n01 = min(min(m[0][0], m[0][1]), m[0][2]);
-                    const int n02 = min(min(n01, m[0][3]), m[1][0]);
-                    const int n03 = min(min(n02, m[1][1]), m[1][2]);
-                    const float nall = __int_as_float(min(n03, m[1][3]));
-                    if (__builtin_expect(__ballot(nall <= bound) != 0ull, 0)) {
+                            if (bb + j)
+                                X = __builtin_amdgcn_bitop3_b32(X, __float_as_uint(acc[8 * bb + j]), __float_as_uint(acc[8 * bb + 4 + j]), 0xE0);
+                    if (__builtin_expect(__ballot(keeps(X)) != 0ull, 0)) {
                         RT_COUNT(3);
                         int colv = col32;
                         asm volatile("" : "+v"(colv));              // keep the address arithmetic on this side of the branch
@@ -653,12 +645,14 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                         unsigned int *row = bits_w + wrel * 64;
 #pragma unroll
                         for (int bb = 0; bb < 2; ++bb) {
-                            const float nG = __int_as_float(min(min(m[bb][0], m[bb][1]), min(m[bb][2], m[bb][3])));
-                            if (__ballot(nG <= bound) != 0ull) {
+                            uint32_t p[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) p[j] = __float_as_uint(acc[8 * bb + j]) | __float_as_uint(acc[8 * bb + 4 + j]);
+                            if (__ballot(keeps((p[0] & p[1]) & (p[2] & p[3]))) != 0ull) {
                                 RT_COUNT(4);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j)
-                                    if (__int_as_float(m[bb][j]) <= bound) {
+                                    if (keeps(p[j])) {
                                         const int ray = 16 * G + 8 * bb + 4 * hh + j;
                                         atomicOr(&row[ray], bit);
                                         atomicOr(&sum_w[ray], wbit);
@@ -680,7 +674,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                     const int t0 = seg0 >> 1;
                     // one 32-sphere tile: four independent MFMAs (one per 16-ray group); two results in
                     // flight so the matrix pipe works on the next group while the VALU looks at this one
-                    auto do_tile = [&](int w, const bf16x8 &b, float bound) {
+                    auto do_tile = [&](int w, const bf16x8 &b) {
                         RT_COUNT(7);
                         // (the empty asm pins the issue order: the scheduler would otherwise sink each MFMA
                         //  below the previous look to share registers, and the wave would sit out the full
@@ -688,39 +682,37 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                         f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], b, zero16, 0, 0, 0);
                         f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], b, zero16, 0, 0, 0);
                         asm volatile("" : "+v"(acc1));
-                        look_tube(0, acc0, bound, w);
+                        look_tube(0, acc0, w);
                         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], b, zero16, 0, 0, 0);
                         asm volatile("" : "+v"(acc0));
-                        look_tube(1, acc1, bound, w);
+                        look_tube(1, acc1, w);
                         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[3], b, zero16, 0, 0, 0);
                         asm volatile("" : "+v"(acc1));
-                        look_tube(2, acc0, bound, w);
-                        look_tube(3, acc1, bound, w);
+                        look_tube(2, acc0, w);
+                        look_tube(3, acc1, w);
                     };
                     if (__builtin_expect(groups == 0xFu, 1)) {
-                        // B operands and bounds ping-pong between two register sets, each fetched a tile ahead
+                        // B operands ping-pong between two register sets, each fetched a tile ahead
                         bf16x8 bp = load_b(t0), bq;
-                        float rp = load_r(t0), rq;
                         int w = 0;
                         for (; w + 1 < nwords; w += 2) {
-                            bq = load_b(t0 + w + 1); rq = load_r(t0 + w + 1);
-                            do_tile(w, bp, rp);
-                            bp = load_b(t0 + w + 2); rp = load_r(t0 + w + 2);
-                            do_tile(w + 1, bq, rq);
+                            bq = load_b(t0 + w + 1);
+                            do_tile(w, bp);
+                            bp = load_b(t0 + w + 2);
+                            do_tile(w + 1, bq);
                         }
-                        if (w < nwords) do_tile(w, bp, rp);
+                        if (w < nwords) do_tile(w, bp);
                     } else {
-                        // end of the launch: some 16-ray groups of this wave have no path left (no more work
-                        // items); only the groups with a ray go through the matrix pipe and the look
+                        // end of the launch / sky rows: some 16-ray groups of this wave have no ray to scan;
+                        // only the groups with one go through the matrix pipe and the look
                         for (int w = 0; w < nwords; ++w) {
                             RT_COUNT(7);
                             const bf16x8 b = load_b(t0 + w);
-                            const float bound = load_r(t0 + w);
 #pragma unroll
                             for (int G = 0; G < 4; ++G)
                                 if (groups & (1u << G)) {
                                     const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[G], b, zero16, 0, 0, 0);
-                                    look_tube(G, acc, bound, w);
+                                    look_tube(G, acc, w);
                                 }
                         }
                     }

@@ -60,7 +60,12 @@ def test_tube_filter_is_sound_and_within_its_budget(renderer):
         o, d, c, r = tube_case(rng, grazing=(it % 3 == 2))
         if it % 5 == 4:
             o[:16] *= 40.0                                   # rays that start far out on the ground sphere
-        h, rows, bound, rho = renderer.filter_tube(o, d, _spheres32(c, r))
+        sp32 = _spheres32(c, r)
+        H, rows, bound, rho = renderer.filter_tube(o, d, sp32)
+        words, _, _ = rt.tube_tile_host(sp32)
+        sigma = (np.array([words[32 + col][2] & 0xFFFF for col in range(32)], dtype=np.uint32) << np.uint32(16)).view(np.float32).astype(np.float64)
+        assert np.all(sigma > 0) and np.all(sigma * bound <= 2.0 * (1.0 - 2.0 ** -6) * (1.0 + 1e-6))
+        h = H / sigma[None, :, None]                        # back to length units
         assert np.all(rows[:, 8] == 1.0)
         u = rows[:, :6].reshape(64, 2, 3).astype(np.float64)
         t = rows[:, 6:8].astype(np.float64)
@@ -76,11 +81,11 @@ def test_tube_filter_is_sound_and_within_its_budget(renderer):
         cn = np.linalg.norm(c, axis=1)
         scale = U * (546.0 * cn[None, :, None] + 33.0 * on[:, None, None])
         worst_eval = max(worst_eval, float(np.max(np.abs(h - hx) / scale)))
-        # (3) the conclusion: the reference can hit  =>  both |h_k| <= bound
+        # (3) the conclusion: the reference can hit  =>  the kernel keeps the pair: both |H_k| < 2
         oc = o[:, None, :] - c[None, :, :]
         hbt = (oc * d[:, None, :]).sum(2)
         disc = hbt ** 2 - (d ** 2).sum(1)[:, None] * ((oc ** 2).sum(2) - (r ** 2)[None, :])
-        keep = np.max(np.abs(h), axis=2) <= bound[None, :]
+        keep = np.max(np.abs(H), axis=2) < 2.0
         assert not np.any((disc >= 0.0) & ~keep)
         kept += int(keep.sum()); total += keep.size; hits += int((disc >= 0.0).sum())
     assert worst_basis < 64.0 and worst_norm < 64.0, (worst_basis, worst_norm)
@@ -96,10 +101,13 @@ def test_tube_columns_and_rays_outside_the_analysed_range(renderer):
     r[4] = 1e-16                         # r^2 <= 1e-30: always kept
     h, rows, bound, rho = renderer.filter_tube(o, d, _spheres32(c, r))
     assert np.isinf(bound[3]) and np.isinf(bound[4]) and np.all(np.isfinite(h))
+    assert np.all(h[:, 3] == 0.0) and np.all(h[:, 4] == 0.0)            # always kept: sigma = 0, H = 0
     assert np.all(bound[np.isfinite(bound)] >= rho)
     o2, d2 = o.copy(), d.copy()
     d2[0] = (1e-11, 0.0, 0.0); d2[1] = (1e11, 0.0, 0.0); o2[2] = (1e16, 0.0, 0.0)
     h, rows, bound, rho = renderer.filter_tube(o2, d2, _spheres32(c, r))
     assert list(rows[:3, 8]) == [0.0, 0.0, 0.0] and np.all(rows[3:, 8] == 1.0)
-    # a ray outside the range is never "kept" by the matrix test (it is tested exhaustively instead)
-    assert np.all(np.max(np.abs(h[:3]), axis=2)[:, np.isfinite(bound)] > bound[np.isfinite(bound)][None, :])
+    # a ray outside the range is never "kept" by the matrix test (it is tested exhaustively instead):
+    # its t = 3e38 times sigma overflows or stays huge
+    big = np.max(np.abs(h[:3]), axis=2)[:, np.isfinite(bound)]
+    assert np.all(~(big < 2.0))

@@ -20,20 +20,30 @@ def make_spheres(rng):
     return sp
 
 
-def test_columns_are_two_exact_bf16_pieces_of_the_f64_centre():
+def sigma_of(words):
+    """(32,) f64: the bf16 scale factor of each column (K-slots 12..14 of the host table)."""
+    return bf16_to_f64(np.array([words[32 + col][2] & 0xFFFF for col in range(32)], dtype=np.uint32))
+
+
+def test_columns_are_two_exact_bf16_pieces_of_sigma_times_the_f64_centre():
     rng = np.random.default_rng(4)
     for _ in range(20):
         sp = make_spheres(rng)
         words, bound, rho = rt.tube_tile_host(sp)
         lo, hi = words & 0xFFFF, words >> 16
+        sigma = sigma_of(words)
+        # sigma = 2 (1 - 2^-6) / bound rounded DOWN to 8 significant bits: "hit => |H| <= sigma bound < 2"
+        target = 2.0 * (1.0 - 2.0 ** -6) / bound.astype(np.float64)
+        assert np.all(sigma <= target * (1.0 + 2.0 ** -23)) and np.all(sigma >= target * (1.0 - 2.0 ** -7))
         for col in range(32):
-            c = sp["center"][col]
+            c = sp["center"][col] * sigma[col]
             k0, k1 = words[col], words[32 + col]           # K-slots 0..7 and 8..15 of this column
             for i, (w_a, w_b) in enumerate([(k0[0], k0[1]), (k0[2], k0[3]), (k1[0], k1[1])]):
                 assert w_a == w_b                           # (y1, y2, y1, y2)
                 y1, y2 = bf16_to_f64(np.uint32(w_a & 0xFFFF)), bf16_to_f64(np.uint32(w_a >> 16))
                 assert abs(c[i] - (y1 + y2)) <= 2.0 ** -16 * abs(c[i])
-            assert k1[2] == 0x3F803F80 and k1[3] == 0x00003F80     # (1, 1, 1, 0) against the pieces of t
+            sg = int(k1[2] & 0xFFFF)
+            assert k1[2] == (sg | (sg << 16)) and k1[3] == sg       # (sigma, sigma, sigma, 0) against the pieces of t and the 1
         assert lo.shape == hi.shape == (64, 4)
 
 
@@ -57,5 +67,5 @@ def test_out_of_range_spheres_are_always_kept_and_carry_no_centre():
     sp["radius"][4] = 1e-16                     # r^2 <= 1e-30
     words, bound, rho = rt.tube_tile_host(sp)
     assert np.isinf(bound[3]) and np.isinf(bound[4])
-    for col in (3, 4):
-        assert not words[col].any() and not words[32 + col][:2].any()
+    for col in (3, 4):                          # sigma = 0 and no centre: H = 0 for every ray, which is "kept"
+        assert not words[col].any() and not words[32 + col].any()
