@@ -10,8 +10,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// KIND 0: v_max_f32 with |.| modifiers (VOP3)   1: v_min3_i32   2: v_add_f32 (VOP2)   MF: issue the MFMA or not
-template <int N, int KIND, bool MF>
+// KIND 0: v_max_f32 with |.| modifiers (VOP3)   1: v_min3_i32   2: v_add_f32 (VOP2)   3: v_bitop3_b32   4: v_or_b32
+// MF: issue the MFMA or not.  AG: the MFMA's A and B operands live in AGPRs (the accumulator half of the register file)
+template <int N, int KIND, bool MF, bool AG = false>
 __global__ __launch_bounds__(256, 4) void k(int iters, float *out)
 {
     const int lane = threadIdx.x & 63;
@@ -24,7 +25,10 @@ __global__ __launch_bounds__(256, 4) void k(int iters, float *out)
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            if (MF) {
+            if (MF && AG) {
+                if (u == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc0) : "a"(a), "a"(b));
+                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc1) : "a"(a), "a"(b));
+            } else if (MF) {
                 if (u == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
                 else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
             }
@@ -32,7 +36,9 @@ __global__ __launch_bounds__(256, 4) void k(int iters, float *out)
             for (int n = 0; n < N; ++n) {
                 if (KIND == 0) asm volatile("v_max_f32_e64 %0, |%0|, |%1|" : "+v"(x[n & 7]) : "v"(y));
                 else if (KIND == 1) asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(x[n & 7]) : "v"(y), "v"(z));
-                else asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(x[n & 7]) : "v"(y));
+                else if (KIND == 2) asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(x[n & 7]) : "v"(y));
+                else if (KIND == 3) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xe0" : "+v"(x[n & 7]) : "v"(y), "v"(z));
+                else asm volatile("v_or_b32_e32 %0, %1, %0" : "+v"(x[n & 7]) : "v"(y));
             }
         }
     }
@@ -41,14 +47,14 @@ __global__ __launch_bounds__(256, 4) void k(int iters, float *out)
     out[blockIdx.x * 256 + threadIdx.x] = r;
 }
 
-template <int N, int KIND, bool MF>
+template <int N, int KIND, bool MF, bool AG = false>
 float run(int cus, int bpc, float *d_out)
 {
     const int iters = 20000;
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((k<N, KIND, MF>), dim3(cus * bpc), dim3(256), 0, 0, 100, d_out);
+    hipLaunchKernelGGL((k<N, KIND, MF, AG>), dim3(cus * bpc), dim3(256), 0, 0, 100, d_out);
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k<N, KIND, MF>), dim3(cus * bpc), dim3(256), 0, 0, iters, d_out);
+    hipLaunchKernelGGL((k<N, KIND, MF, AG>), dim3(cus * bpc), dim3(256), 0, 0, iters, d_out);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -78,5 +84,12 @@ int main()
     row<28, 1>("v_min3_i32", cus, d_out);
     row<14, 2>("v_add_f32", cus, d_out);
     row<28, 2>("v_add_f32", cus, d_out);
+    row<9, 3>("v_bitop3_b32", cus, d_out);
+    row<18, 3>("v_bitop3_b32", cus, d_out);
+    row<9, 4>("v_or_b32", cus, d_out);
+    printf("-- MFMA with A and B in AGPRs: cycles per unit at 1, 2, 4 waves/SIMD --\n");
+    printf("v_add_f32    N=14   %6.1f %6.1f %6.1f\n", run<14, 2, true, true>(cus, 1, d_out), run<14, 2, true, true>(cus, 2, d_out), run<14, 2, true, true>(cus, 4, d_out));
+    printf("v_bitop3_b32 N= 9   %6.1f %6.1f %6.1f\n", run<9, 3, true, true>(cus, 1, d_out), run<9, 3, true, true>(cus, 2, d_out), run<9, 3, true, true>(cus, 4, d_out));
+    printf("v_max|f32|   N=14   %6.1f %6.1f %6.1f\n", run<14, 0, true, true>(cus, 1, d_out), run<14, 0, true, true>(cus, 2, d_out), run<14, 0, true, true>(cus, 4, d_out));
     return 0;
 }

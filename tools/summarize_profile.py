@@ -17,12 +17,13 @@ for cfg, shape in CONFIGS.items():
         continue
     out = {"command": "python3 " + open(os.path.join(prof, "command.txt")).read().strip(), "config": shape,
            "kernel_source_sha": bench.kernel_source_sha()}
-    ks = glob.glob(os.path.join(prof, "trace", "*", "*_kernel_stats.csv"))[0]
+    newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)     # gpurun MERGES runs into gpurun_out/: take the latest
+    ks = newest(os.path.join(prof, "trace", "*", "*_kernel_stats.csv"))
     shutil.copy(ks, os.path.join(root, "profiles", f"{tag}_kernel_stats_{cfg}.csv"))
     rows = list(csv.DictReader(open(ks)))
     out["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage") if k in r} for r in rows[:5]]
     pm = {}
-    for f in sorted(glob.glob(os.path.join(prof, "pmc*", "*", "*_counter_collection.csv"))):
+    for f in [newest(os.path.join(d, "*", "*_counter_collection.csv")) for d in sorted(glob.glob(os.path.join(prof, "pmc[0-9]*"))) if os.path.isdir(d)]:
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if "render_kernel" in r["Kernel_Name"]:
