@@ -9,7 +9,7 @@
 #define BODY16(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
 
 template <int KIND>
-__global__ __launch_bounds__(256, 4) void k(int iters, float *out, unsigned sk)
+__global__ __launch_bounds__(256, 4) void k(int iters, float *out, unsigned sk, double sd, unsigned long long m64)
 {
     const int lane = threadIdx.x & 63;
     float x[8];
@@ -45,6 +45,14 @@ __global__ __launch_bounds__(256, 4) void k(int iters, float *out, unsigned sk)
 #define S_CVT(i) asm volatile("v_cvt_f64_u32_e32 %0, %1" : "=v"(d[i]) : "v"(x[i]));
 #define S_ADDU(i) asm volatile("v_add_u32_e32 %0, %1, %0" : "+v"(x[i]) : "v"(y));
 #define S_MAX3ABS(i) asm volatile("v_max3_f32 %0, |%0|, |%1|, |%2|" : "+v"(x[i]) : "v"(y), "v"(z));
+#define S_MAD64S(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "+v"(d[i]) : "v"(y), "s"(sk) : "vcc");
+#define S_BITOP3S0(i) asm volatile("v_bitop3_b32 %0, %2, %0, %1 bitop3:0x96" : "+v"(x[i]) : "v"(y), "s"(sk));
+#define S_MULF64S(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[i]) : "s"(sd));
+#define S_ADDF64S(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i]) : "s"(sd));
+#define S_MADI64(i) asm volatile("v_mad_i64_i32 %0, vcc, %1, %1, %0" : "+v"(d[i]) : "v"(y) : "vcc");
+#define S_OR(i) asm volatile("v_or_b32_e32 %0, %1, %0" : "+v"(x[i]) : "v"(y));
+#define S_CMPABS(i) asm volatile("v_cmp_lt_f32_e64 vcc, |%0|, 2.0" : : "v"(x[i]) : "vcc");
+#define S_CNDE64(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x[i]) : "v"(y), "s"(m64));
         if (KIND == 0) { BODY16(S_ADD32) } else if (KIND == 1) { BODY16(S_ADD64E) } else if (KIND == 2) { BODY16(S_MAX32) }
         else if (KIND == 3) { BODY16(S_MAX64) } else if (KIND == 4) { BODY16(S_MAXABS) } else if (KIND == 5) { BODY16(S_MINI) }
         else if (KIND == 6) { BODY16(S_MIN3) } else if (KIND == 7) { BODY16(S_ANDS) } else if (KIND == 8) { BODY16(S_ANDL) }
@@ -54,6 +62,9 @@ __global__ __launch_bounds__(256, 4) void k(int iters, float *out, unsigned sk)
         else if (KIND == 18) { BODY16(S_FMAF64) } else if (KIND == 19) { BODY16(S_LSHLADD) } else if (KIND == 20) { BODY16(S_MOV) }
         else if (KIND == 21) { BODY16(S_MULF32) } else if (KIND == 22) { BODY16(S_FMAF32) } else if (KIND == 23) { BODY16(S_CVT) }
         else if (KIND == 24) { BODY16(S_ADDU) } else if (KIND == 25) { BODY16(S_MAX3ABS) }
+        else if (KIND == 26) { BODY16(S_MAD64S) } else if (KIND == 27) { BODY16(S_BITOP3S0) } else if (KIND == 28) { BODY16(S_MULF64S) }
+        else if (KIND == 29) { BODY16(S_ADDF64S) } else if (KIND == 30) { BODY16(S_MADI64) } else if (KIND == 31) { BODY16(S_OR) }
+        else if (KIND == 32) { BODY16(S_CMPABS) } else if (KIND == 33) { BODY16(S_CNDE64) }
     }
     float r = (float)acc64;
     for (int i = 0; i < 8; ++i) r += x[i] + (float)d[i];
@@ -68,9 +79,9 @@ void run(const char *name, int cus, float *d_out)
     int w = 0;
     for (int bpc : {1, 2, 4}) {
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(k<KIND>, dim3(cus * bpc), dim3(256), 0, 0, 100, d_out, 0x7fffffffu);
+        hipLaunchKernelGGL(k<KIND>, dim3(cus * bpc), dim3(256), 0, 0, 100, d_out, 0x7fffffffu, 1.0000001, 0x5555555555555555ull);
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k<KIND>, dim3(cus * bpc), dim3(256), 0, 0, iters, d_out, 0x7fffffffu);
+        hipLaunchKernelGGL(k<KIND>, dim3(cus * bpc), dim3(256), 0, 0, iters, d_out, 0x7fffffffu, 1.0000001, 0x5555555555555555ull);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -99,6 +110,12 @@ int main()
     run<11>("v_bitop3_b32", cus, d_out);
     run<12>("v_bitop3_b32 sgpr", cus, d_out);
     run<13>("v_mad_u64_u32", cus, d_out);
+    run<26>("v_mad_u64_u32 sgpr multiplier", cus, d_out);
+    run<30>("v_mad_i64_i32", cus, d_out);
+    run<27>("v_bitop3_b32 sgpr as src0", cus, d_out);
+    run<31>("v_or_b32_e32", cus, d_out);
+    run<32>("v_cmp_lt_f32_e64 |x|, 2.0", cus, d_out);
+    run<33>("v_cndmask_b32_e64 (sgpr mask)", cus, d_out);
     run<14>("v_cndmask_b32_e32", cus, d_out);
     run<15>("v_cmp_ge_f32_e32", cus, d_out);
     run<24>("v_add_u32_e32", cus, d_out);
@@ -109,6 +126,8 @@ int main()
     run<23>("v_cvt_f64_u32_e32", cus, d_out);
     run<16>("v_add_f64", cus, d_out);
     run<17>("v_mul_f64", cus, d_out);
+    run<28>("v_mul_f64 sgpr operand", cus, d_out);
+    run<29>("v_add_f64 sgpr operand", cus, d_out);
     run<18>("v_fma_f64", cus, d_out);
     return 0;
 }
