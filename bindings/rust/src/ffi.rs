@@ -136,5 +136,7 @@ extern "C" {
                                  out_h: *mut f32, out_rows: *mut f32, out_bound: *mut f32, out_rho: *mut f32) -> i32;
     pub fn rt_tube_tile_host(spheres32: *const rt_sphere, out_words: *mut u32, out_bound: *mut f32,
                              out_rho: *mut f32) -> i32;
+    pub fn rt_tile_layout_host(spheres: *const rt_sphere, n: i32, out_dims: *mut i32, out_grid: *mut f32,
+                               out_slot_of: *mut i32, cap: i32) -> i32;
     pub fn rt_philox_device(ctx: *mut rt_context, ctr: *const u32, key: *const u32, out: *mut u32) -> i32;
 }

@@ -217,6 +217,15 @@ int rt_filter_tube_device(rt_context *ctx, const double *o, const double *d, con
  * word, low half first): slots 0..11 two bf16 pieces of sigma * centre per coordinate as (y1, y2, y1, y2),
  * slots 12..14 sigma, slot 15 zero (4.0 in a column no ray may keep); out_bound: [32]; out_rho: the radius floor. */
 int rt_tube_tile_host(const rt_sphere *spheres32, uint32_t *out_words, float *out_bound, float *out_rho);
+/* Where rt_upload_scene puts each sphere in the filter's table of columns, no device needed.  The table is made
+ * of tiles of 32 columns: tiles [0, n_global) are scanned for every ray (spheres too large for a grid cell, and what
+ * did not fit its cell's tile); tile n_global + iz * grid_dim + ix holds spheres whose centre lies in cell (ix, iz)
+ * of a square grid over x and z.  out_dims = (grid_dim, n_global), grid_dim 0: no grid, columns in list order;
+ * out_grid = (x0, z0, 1 / cell size, x1, z1, y lo, y hi, largest radius in a cell): every sphere of a cell tile has
+ * its centre in that cell, its radius <= out_grid[7] and its extent in y within [out_grid[5], out_grid[6]];
+ * out_slot_of[column] = the sphere's place in the list, -1 for padding.  Spheres on the always-exact list are in no
+ * column.  Returns the number of columns (a multiple of 32, <= cap) or a negative RT_ERR_*. */
+int rt_tile_layout_host(const rt_sphere *spheres, int32_t n, int32_t out_dims[2], float out_grid[8], int32_t *out_slot_of, int32_t cap);
 int rt_philox_device(rt_context *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 #ifdef __cplusplus

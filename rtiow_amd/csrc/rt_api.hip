@@ -54,6 +54,11 @@ struct rt_context {
     double *d_mat = nullptr;       // [n][kMatStride] exact materials
     uint4 *d_btube = nullptr;      // [tiles/2 + 1][64] MODE 5 (tube filter) B operands
     float tube_rho = 1.0f;         // MODE 5 radius floor
+    double *d_geo_slot = nullptr;  // MODE 5: [slots][4] exact geometry in table (slot) order
+    uint32_t *d_slot_orig = nullptr;   // MODE 5: [slots] list index of the sphere in each column of the table
+    int n_global = 0;              // MODE 5: tiles [0, n_global) are scanned for every ray; the rest are grid cells
+    int grid_dim = 0;              // MODE 5: cells per side of the xz grid (0: no grid, every tile is scanned)
+    float grid[8] = {};            // x0, z0, 1/cell, x1, z1, y lo, y hi, pad (rt_device.hpp, mark_grid_cells)
     float boxes[rt::kMaxBoxes][6] = {};   // MODE 5: boxes that hold every scanned sphere (lo xyz, hi xyz)
     float box_scale = 0.0f;
     int n_boxes = 0;
@@ -276,8 +281,8 @@ void tube_tile(const rt_sphere *const s[32], float rho, uint4 out_b[64], float o
 void free_scene(rt_context *ctx)
 {
     (void)hipFree(ctx->d_filt); (void)hipFree(ctx->d_geo); (void)hipFree(ctx->d_mat);
-    (void)hipFree(ctx->d_btube);
-    ctx->d_filt = nullptr; ctx->d_geo = ctx->d_mat = nullptr; ctx->d_btube = nullptr;
+    (void)hipFree(ctx->d_btube); (void)hipFree(ctx->d_geo_slot); (void)hipFree(ctx->d_slot_orig);
+    ctx->d_filt = nullptr; ctx->d_geo = ctx->d_mat = nullptr; ctx->d_btube = nullptr; ctx->d_geo_slot = nullptr; ctx->d_slot_orig = nullptr;
 #ifdef RTIOW_CROSSCHECK_MODES
     (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt); (void)hipFree(ctx->d_bmat16); (void)hipFree(ctx->d_kpt16);
     (void)hipFree(ctx->d_bmatL);
@@ -315,6 +320,132 @@ int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, in
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(ctx->ev1, stream));
     return RT_OK;
+}
+
+// Where MODE 5 puts each sphere in its table of columns (tiles of 32), and the grid the kernel finds tiles with.
+struct TileLayout {
+    int grid_dim = 0, n_global = 0;
+    float grid[8] = {};             // rt_kernels.hpp, KParams::grid
+    float scale = 0.0f;             // sum over axes of the largest |coordinate| of the grid's box
+    std::vector<int> slot_of;       // column -> place in the caller's list, -1 = padding; a multiple of 32 long
+};
+
+// The spheres that skip the filter and are always tested exactly: much larger than the rest of the scene (the
+// ground), the filter would keep them for nearly every ray.  The choice only moves work, never results.
+std::vector<int> always_exact_list(const rt_sphere *spheres, int n)
+{
+    std::vector<int> out;
+    if (n <= 0) return out;
+    std::vector<double> radii(n);
+    for (int i = 0; i < n; ++i) radii[i] = std::fabs(spheres[i].radius);
+    std::vector<double> sorted = radii;
+    std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+    const double big = 8.0 * sorted[n / 2];
+    std::vector<int> order;
+    for (int i = 0; i < n; ++i) if (radii[i] > big) order.push_back(i);
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return radii[x] > radii[y]; });
+    for (size_t k = 0; k < order.size() && k < 8; ++k) out.push_back(order[k]);
+    return out;
+}
+
+TileLayout tile_layout(const rt_sphere *spheres, int n, const char *never)
+{
+    TileLayout L;
+    // ---- which column of the table holds which sphere --------------------------------------------------
+    // Spheres are put into tiles of 32 columns by WHERE they are, so that a wave only scans the tiles its rays
+    // can reach (rt_device.hpp, mark_grid_cells): a square grid over the xz extent of the small spheres, one tile
+    // per cell (about 20 spheres per cell on average; what does not fit a cell's 32 columns overflows), preceded
+    // by "global" tiles that every ray scans: spheres too large for a cell and the overflow.  The order of the
+    // columns decides nothing: ties are resolved on the spheres' positions in the caller's list (slot_orig).
+    std::vector<int> filtered;
+    for (int i = 0; i < n; ++i) if (!never[i]) filtered.push_back(i);
+    std::vector<int> &slot_of = L.slot_of;
+    L.grid_dim = 0; L.n_global = 0;
+    if (filtered.size() > 64 && !env_int("RTIOW_NO_GRID", 0)) {
+        std::vector<double> rr;
+        for (int i : filtered) rr.push_back(std::fabs(spheres[i].radius));
+        std::nth_element(rr.begin(), rr.begin() + rr.size() / 2, rr.end());
+        const double med = rr[rr.size() / 2];
+        double x0 = INFINITY, x1 = -INFINITY, z0 = INFINITY, z1 = -INFINITY;
+        for (int i : filtered) {
+            if (std::fabs(spheres[i].radius) > 3.0 * med) continue;
+            x0 = std::min(x0, spheres[i].center[0]); x1 = std::max(x1, spheres[i].center[0]);
+            z0 = std::min(z0, spheres[i].center[2]); z1 = std::max(z1, spheres[i].center[2]);
+        }
+        const double extent = std::max(x1 - x0, z1 - z0);
+        // cells(G): the spheres of each cell of a G x G grid, and what does not go into a cell
+        std::vector<std::vector<int>> cells;
+        std::vector<int> global;
+        double cell = 1.0;
+        auto assign = [&](int G, bool keep) -> int {       // -> number of global tiles
+            cell = (extent > 0.0 && extent < 1e15) ? extent / G : 1.0;
+            std::vector<int> count((size_t)G * G, 0);
+            if (keep) { cells.assign((size_t)G * G, {}); global.clear(); }
+            size_t n_glob = 0;
+            for (int i : filtered) {
+                const double r = std::fabs(spheres[i].radius);
+                bool to_cell = !(r > 3.0 * med || r > 0.25 * cell);
+                size_t c = 0;
+                if (to_cell) {
+                    int ix = (int)std::floor((spheres[i].center[0] - x0) / cell), iz = (int)std::floor((spheres[i].center[2] - z0) / cell);
+                    ix = std::max(0, std::min(ix, G - 1)); iz = std::max(0, std::min(iz, G - 1));
+                    c = (size_t)iz * G + ix;
+                    to_cell = count[c] < 32;                        // the cell's tile is full: overflow
+                }
+                if (to_cell) { ++count[c]; if (keep) cells[c].push_back(i); }
+                else { ++n_glob; if (keep) global.push_back(i); }
+            }
+            return (int)((n_glob + 31) / 32);
+        };
+        // The grid's resolution: a wave scans the global tiles plus the cells its 64 rays touch, and rays are lines --
+        // the cells touched grow like G (measured on the book scenes: about 1.4 G - 1.6 of G x G), while coarse cells
+        // overflow into global tiles.  Take the G with the smallest  global tiles + 1.4 G.
+        int G = env_int("RTIOW_GRID_DIM", 0);
+        if (G <= 0) {
+            double best = INFINITY;
+            for (int g = 1; g <= 42; ++g) {
+                if ((double)g * g > (double)filtered.size()) break;
+                const int ng = assign(g, false);
+                if (ng > 48) continue;                              // (the kernel's list holds 126 tiles)
+                const double cost = ng + 1.4 * g;
+                if (cost < best) { best = cost; G = g; }
+            }
+        }
+        G = std::max(1, std::min(G, 42));                   // (no G qualified: G = 1 will not either, and the grid stays off)
+        (void)assign(G, true);
+        double ylo = INFINITY, yhi = -INFINITY, pad = 0.0;
+        for (const std::vector<int> &c : cells)
+            for (int i : c) {
+                const double r = std::fabs(spheres[i].radius);
+                ylo = std::min(ylo, spheres[i].center[1] - r); yhi = std::max(yhi, spheres[i].center[1] + r);
+                pad = std::max(pad, r);
+            }
+        const int n_global = (int)((global.size() + 31) / 32);
+        if ((size_t)(n_global + G * G) * 32 <= 65536 && n_global <= 48 && ylo <= yhi) {
+            L.grid_dim = G; L.n_global = n_global;
+            slot_of.assign((size_t)(n_global + G * G) * 32, -1);
+            for (size_t k = 0; k < global.size(); ++k) slot_of[k] = global[k];
+            for (size_t c = 0; c < cells.size(); ++c)
+                for (size_t k = 0; k < cells[c].size(); ++k) slot_of[((size_t)n_global + c) * 32 + k] = cells[c][k];
+            auto down = [](double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -INFINITY); return f; };
+            auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; };
+            L.grid[0] = down(x0); L.grid[1] = down(z0);
+            // the kernel turns a coordinate into a cell with THESE f32 values; rounding 1/cell either way only
+            // shifts cell borders by ~1e-7 cells, which the kernel's own margin (1e-3 cells) covers
+            L.grid[2] = (float)(1.0 / cell);
+            L.grid[3] = up(x0 + G * cell); L.grid[4] = up(z0 + G * cell);
+            L.grid[5] = down(ylo); L.grid[6] = up(yhi); L.grid[7] = up(pad);
+            // the kernel's error margins are relative to the size of what a ray can reach: the boxes and the grid
+            const double gs = std::max(std::fabs(x0), std::fabs(x0 + G * cell)) + pad + std::max(std::fabs(ylo), std::fabs(yhi)) +
+                              std::max(std::fabs(z0), std::fabs(z0 + G * cell)) + pad;
+            L.scale = (float)gs * 1.0001f;
+        }
+    }
+    if (L.grid_dim == 0) {                              // no grid: the columns in list order, every tile scanned
+        slot_of.assign((size_t)((filtered.empty() ? 0 : filtered.back() + 1) + 31) / 32 * 32, -1);
+        for (int i : filtered) slot_of[i] = i;
+    }
+    return L;
 }
 
 } // namespace
@@ -431,20 +562,9 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
             m[2] = 1.0; m[3] = 1.0; m[4] = 1.0;                                  // attenuation (1,1,1), :103
         }
     }
-    // Spheres much larger than the rest of the scene (the ground) are kept by the filter for nearly
-    // every ray: they skip it and are always tested exactly.  The choice only moves work, never results.
+    // the spheres that skip the filter (always_exact_list above)
     ctx->n_always = 0;
-    if (n > 0) {
-        std::vector<double> radii(n);
-        for (int i = 0; i < n; ++i) radii[i] = std::fabs(spheres[i].radius);
-        std::vector<double> sorted = radii;
-        std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
-        const double big = 8.0 * sorted[n / 2];
-        std::vector<int> order;
-        for (int i = 0; i < n; ++i) if (radii[i] > big) order.push_back(i);
-        std::sort(order.begin(), order.end(), [&](int x, int y) { return radii[x] > radii[y]; });
-        for (size_t k = 0; k < order.size() && k < 8; ++k) ctx->always_idx[ctx->n_always++] = order[k];
-    }
+    for (int i : always_exact_list(spheres, n)) ctx->always_idx[ctx->n_always++] = i;
     // tile count (tiles of 16 columns) rounded up to even, plus two spare tiles so the pipelined loops
     // never branch on a table bound (padding columns are never kept)
     const int n_tiles = 2 * ((n + 31) / 32);
@@ -452,9 +572,6 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
     int rc = RT_OK;
     // Only the table of the scan mode this context runs is built (RTIOW_SCAN_MODE, read at rt_create).
     if (ctx->scan_mode == 5) {      // the tube filter (shipped)
-        const size_t ttc = (size_t)n_tiles / 2 + 1;
-        std::vector<uint4> btube(ttc * 64);
-        std::vector<float> rtube(ttc * 32);
         std::vector<char> never(n > 0 ? n : 1, 0);
         for (int e = 0; e < ctx->n_always; ++e) never[ctx->always_idx[e]] = 1;
         ctx->tube_rho = tube_radius_floor(spheres, n, never.data());
@@ -507,15 +624,35 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
             if (any_rest) add_box(lo, hi);
             ctx->box_scale = (float)(scale[0] + scale[1] + scale[2]) * 1.0001f;
         }
+        // which column of the table holds which sphere, and the grid the kernel finds tiles with
+        const TileLayout L = tile_layout(spheres, n, never.data());
+        const std::vector<int> &slot_of = L.slot_of;
+        ctx->grid_dim = L.grid_dim; ctx->n_global = L.n_global;
+        for (int k = 0; k < 8; ++k) ctx->grid[k] = L.grid[k];
+        ctx->box_scale = std::max(ctx->box_scale, L.scale);
+        const int n_tiles32 = (int)(slot_of.size() / 32);
+        ctx->n_tiles = 2 * n_tiles32;                          // (counted in 16-column units, as the other scan modes do)
+        const size_t ttc = (size_t)n_tiles32 + 1;              // one spare tile: the pipelined loop never branches on a table bound
+        std::vector<uint4> btube(ttc * 64);
+        std::vector<float> rtube(ttc * 32);
+        std::vector<double> geo_slot(ttc * 32 * 4, 0.0);
+        std::vector<uint32_t> slot_orig(ttc * 32, 0xFFFFFFFFu);
         for (size_t t = 0; t < ttc; ++t) {
             const rt_sphere *col[32];
             for (int c = 0; c < 32; ++c) {
-                const long i = 32 * (long)t + c;
-                col[c] = (i < n && !never[i]) ? &spheres[i] : nullptr;
+                const size_t slot = 32 * t + c;
+                const int i = slot < slot_of.size() ? slot_of[slot] : -1;
+                col[c] = i >= 0 ? &spheres[i] : nullptr;
+                if (i >= 0) {
+                    slot_orig[slot] = (uint32_t)i;
+                    for (int k = 0; k < 4; ++k) geo_slot[4 * slot + k] = geo[4 * (size_t)i + k];
+                }
             }
             tube_tile(col, ctx->tube_rho, &btube[t * 64], &rtube[t * 32]);
         }
         if (!rc) rc = upload_table(&ctx->d_btube, btube.data(), btube.size());
+        if (!rc) rc = upload_table(&ctx->d_geo_slot, geo_slot.data(), geo_slot.size());
+        if (!rc) rc = upload_table(&ctx->d_slot_orig, slot_orig.data(), slot_orig.size());
     }
     // filter records of the f32 evaluation schemes (mode 1, and the sources of the mode 2/3 tables):
     // centre rounded to f32 + K'
@@ -652,6 +789,11 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.bmat16 = ctx->d_bmat16; kp.kpt16 = ctx->d_kpt16; kp.bmatL = ctx->d_bmatL;
 #endif
     kp.btube = ctx->d_btube; kp.tube_rho = ctx->tube_rho;
+    kp.geo_slot = ctx->d_geo_slot; kp.slot_orig = ctx->d_slot_orig;
+    kp.n_global = ctx->n_global; kp.grid_dim = ctx->grid_dim;
+    kp.grid_rows = 0ull;
+    for (int k = 0; ctx->grid_dim > 0 && (k + 1) * ctx->grid_dim <= 64; ++k) kp.grid_rows |= 1ull << (k * ctx->grid_dim);
+    for (int k = 0; k < 8; ++k) kp.grid[k] = ctx->grid[k];
     memcpy(kp.boxes, ctx->boxes, sizeof(kp.boxes));
     kp.box_scale = ctx->box_scale;
     kp.n_boxes = env_int("RTIOW_NO_BOX_CULL", 0) ? -1 : ctx->n_boxes;      // (diagnostic A/B: -1 = never cull)
@@ -937,6 +1079,19 @@ int rt_filter_tube_device(rt_context *ctx, const double *o, const double *d, con
     RT_HIP(hipMemcpyAsync(out_rows, d_rows, 64 * 9 * 4, hipMemcpyDeviceToHost, ctx->own_stream));
     RT_HIP(hipStreamSynchronize(ctx->own_stream));
     return RT_OK;
+}
+
+int rt_tile_layout_host(const rt_sphere *spheres, int32_t n, int32_t out_dims[2], float out_grid[8], int32_t *out_slot_of, int32_t cap)
+{
+    if (!spheres || n < 0 || n > 65535 || !out_dims || !out_grid || (!out_slot_of && cap > 0)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_tile_layout_host: bad argument");
+    std::vector<char> never(n > 0 ? n : 1, 0);
+    for (int i : always_exact_list(spheres, n)) never[i] = 1;
+    const TileLayout L = tile_layout(spheres, n, never.data());
+    out_dims[0] = L.grid_dim; out_dims[1] = L.n_global;
+    for (int k = 0; k < 8; ++k) out_grid[k] = L.grid[k];
+    if ((size_t)cap < L.slot_of.size()) return fail(RT_ERR_INVALID_ARGUMENT, "rt_tile_layout_host: out_slot_of too small");
+    for (size_t k = 0; k < L.slot_of.size(); ++k) out_slot_of[k] = L.slot_of[k];
+    return (int)L.slot_of.size();
 }
 
 int rt_philox_device(rt_context *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])

@@ -392,6 +392,51 @@ __device__ __forceinline__ bool ray_may_reach_boxes(D3 o, D3 d, const float (&bo
     return any;
 }
 
+// MODE 5 tiles its spheres by position: a square grid of G x G cells over x in [g0, g3], z in [g1, g4] (cell size
+// 1 / g2), and every sphere that lives in a cell has its centre in that cell, radius <= g7 and its whole extent within
+// y in [g5, g6] (rt_api.hip).  Which cells can hold a sphere the ray o + t d, t > 0, hits?  The hit point lies on the
+// ray, inside the slab g5 <= y <= g6 and within g7 of the sphere's centre in x and z: so clip the ray to the box
+// [g0 - g7, g3 + g7] x [g5, g6] x [g1 - g7, g4 + g7], take the xz bounding rectangle of the clipped piece, grow it by
+// g7 and return the cells it overlaps: columns ix0 .. ix0 + nx - 1, rows iz0 .. iz0 + nz - 1; the return value is
+// nx * nz, 0 when the ray misses the box, -1 when the question cannot be answered (the wave then scans every tile).
+// f32 arithmetic, biased to include: the margins of ray_may_reach_boxes (e on every face of the box, the 0.9999 on the
+// interval); the two end points carry the slab parameters' error (<= 3e-7 relative, on a length <= |o| + the scene's
+// size) and their own rounding: 3 e more; the cell coordinates are rounded by 1e-3 cells outwards.
+__device__ __forceinline__ int grid_cells(D3 o, D3 d, const float (&g)[8], int G, float scale, int &ix0, int &nx, int &iz0, int &nz)
+{
+    const float of[3] = {(float)o.x, (float)o.y, (float)o.z};
+    const float df[3] = {(float)d.x, (float)d.y, (float)d.z};
+    const float o1 = __builtin_fabsf(of[0]) + __builtin_fabsf(of[1]) + __builtin_fabsf(of[2]);
+    const float e = 1e-6f * (o1 + scale);
+    const float dmin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(df[0]), __builtin_fabsf(df[1])), __builtin_fabsf(df[2]));
+    const float dmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(df[0]), __builtin_fabsf(df[1])), __builtin_fabsf(df[2]));
+    if (!(dmin > 1e-30f && dmax < 1e15f && o1 < 1e15f)) return -1;
+    const float m = g[7] + e;
+    const float lo[3] = {g[0] - m, g[5] - e, g[1] - m}, hi[3] = {g[3] + m, g[6] + e, g[4] + m};
+    float t_in = 0.0f, t_out = __builtin_inff();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float inv = __builtin_amdgcn_rcpf(df[a]);
+        const float t0 = (lo[a] - of[a]) * inv, t1 = (hi[a] - of[a]) * inv;
+        t_in = __builtin_fmaxf(t_in, __builtin_fminf(t0, t1));
+        t_out = __builtin_fminf(t_out, __builtin_fmaxf(t0, t1));
+    }
+    if (t_out < t_in * 0.9999f) return 0;
+    if (!(t_out < 1e30f)) return -1;
+    const float m2 = g[7] + 4.0f * e;
+    const float xa = __builtin_fmaf(t_in, df[0], of[0]), xb = __builtin_fmaf(t_out, df[0], of[0]);
+    const float za = __builtin_fmaf(t_in, df[2], of[2]), zb = __builtin_fmaf(t_out, df[2], of[2]);
+    const float fx0 = ((__builtin_fminf(xa, xb) - m2) - g[0]) * g[2] - 1e-3f, fx1 = ((__builtin_fmaxf(xa, xb) + m2) - g[0]) * g[2] + 1e-3f;
+    const float fz0 = ((__builtin_fminf(za, zb) - m2) - g[1]) * g[2] - 1e-3f, fz1 = ((__builtin_fmaxf(za, zb) + m2) - g[1]) * g[2] + 1e-3f;
+    if (!(fx0 <= fx1 && fz0 <= fz1)) return -1;                                         // (a NaN)
+    // (float -> int conversions saturate; the cells are clamped to the grid like the host clamps the centres)
+    ix0 = min(max((int)__builtin_floorf(fx0), 0), G - 1);
+    iz0 = min(max((int)__builtin_floorf(fz0), 0), G - 1);
+    nx = min(max((int)__builtin_floorf(fx1), 0), G - 1) - ix0 + 1;
+    nz = min(max((int)__builtin_floorf(fz1), 0), G - 1) - iz0 + 1;
+    return nx * nz;
+}
+
 struct TubeRay {
     float u[2][3];      // lambda * u_k
     float t[2];         // -(lambda u_k) . o

@@ -16,9 +16,11 @@
 //     conservative FILTER (rt_device.hpp) -- it may send a sphere to the exact
 //     test needlessly, never drop one the reference would hit.  The shipped form
 //     (MODE 5, the tube filter) evaluates it on the bf16 matrix pipe, 16 rays x 2
-//     directions x 32 spheres per instruction; MODEs 1-4 (VALU + scalar loads, f32
-//     matrix pipe, two quadratic forms on the bf16 matrix pipe) are kept as
-//     cross-checks, MODE 0 has no filter at all;
+//     directions x 32 spheres per instruction, and only over the tiles of spheres the wave's
+//     rays can reach (the table is tiled by position: a grid over x and z, rt_device.hpp
+//     grid_cells); MODE 1 (VALU + scalar loads) and MODE 0 (no filter at all) are the
+//     validation modes of the product build, MODEs 2-4 (earlier matrix-pipe forms) exist
+//     only in the cross-check build (-DRTIOW_CROSSCHECK_MODES);
 //   * spheres the filter keeps are marked in per-ray LDS bitmaps, pooled over the
 //     wave and put through the reference's exact f64 test (sphere.rs:16-34), so every
 //     hit decision and every shading value is the reference's own f64 arithmetic;
@@ -72,6 +74,14 @@ struct KParams {
     float boxes[4][6];         // [k] = lo x, y, z, hi x, y, z
     float box_scale;           // sum over axes of the largest |coordinate| of any box
     int32_t n_boxes;
+    // MODE 5: the table's columns are ordered by position (rt_api.hip): tiles [0, n_global) hold the spheres every
+    // ray scans, tile n_global + iz * grid_dim + ix those whose centre lies in cell (ix, iz) of a square xz grid.
+    const double *geo_slot;    // [columns][4] exact (cx, cy, cz, r*r) in column order
+    const uint32_t *slot_orig; // [columns] place in the caller's list of the sphere in each column
+    float grid[8];             // x0, z0, 1/cell, x1, z1, y lo, y hi, largest radius of a sphere that lives in a cell
+    int32_t grid_dim;          // cells per side; 0: no grid (every tile is scanned, columns in list order)
+    unsigned long long grid_rows;      // bit k * grid_dim for every k with (k + 1) * grid_dim <= 64 (grids of <= 64 cells)
+    int32_t n_global;
     int32_t n_tiles;
     int32_t n_always;          // spheres that skip the filter and are always tested exactly
     int32_t always_idx[8];
@@ -91,6 +101,7 @@ constexpr int kRingSlots = 8;       // pixels a block may touch when its sums ar
 constexpr int kRingMinSpp = 37;     //   ... which holds from 37 spp per launch on; below that samples go to the frame buffer one by one
 constexpr int kRingDepth = 4;       // blocks of one wave that may be unfinished at the same time (older ones: see `orphan`)
 constexpr int kMatStride = 10;      // doubles per material record
+constexpr int kListCap = 126;       // MODE 5: longest list of tiles a wave scans by list; beyond, it scans the whole table
 constexpr int kSegTiles = 36;       // matrix filter: tiles (of 16 spheres) per candidate-bitmap segment
 
 __device__ __forceinline__ D3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
@@ -150,6 +161,8 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
     static_assert((kSegTiles / 2) * 64 * sizeof(unsigned int) >= 32 * kStageStride * sizeof(uint4), "operand staging fits the bitmap");
     static_assert((kSegTiles / 2) * 64 * sizeof(unsigned int) >= 64 * 4 * sizeof(uint4), "tube operand staging fits the bitmap");
     __shared__ __attribute__((aligned(16))) unsigned int s_bits[MATRIX ? kBlock / 64 : 1][MATRIX ? kSegTiles / 2 : 1][MATRIX ? 64 : 1];
+    __shared__ unsigned long long s_tmask[TUBE ? kBlock / 64 : 1][TUBE ? 64 : 1];   // MODE 5: per wave and grid row, which cells its rays reach
+    __shared__ unsigned int s_tlist[TUBE ? kBlock / 64 : 1][TUBE ? kListCap + 2 : 1];   //   ... and the tiles of those cells
     __shared__ unsigned int s_sum[MATRIX ? kBlock : 1];     // per ray: which of its bitmap words are non-zero
     // pooled exact tests: ring of waiting (ray << 16 | sphere) pairs per wave; per-ray minimum root and its sphere
     __shared__ unsigned int s_pool[MATRIX ? kBlock / 64 : 1][MATRIX ? 128 : 1];
@@ -332,7 +345,6 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
             // Block 0 = (u jitter, v jitter, lens x, lens y); every further block holds TWO tries.
             uint32_t wx = w.z, wy = w.w;
             while (!unit_disk_accepts(wx, wy)) {
-                RT_COUNT(2);
                 w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
                 ev++;
                 wx = w.x; wy = w.y;
@@ -507,7 +519,11 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 const uint32_t e_i = pool_done + (uint32_t)lane;
                 const bool act = e_i < pool_n;
                 const uint32_t e = act ? pool_w[e_i & 127u] : ((uint32_t)lane << 16);
-                const int r = (int)(e >> 16), idx = (int)(e & 0xFFFFu);
+                const int r = (int)(e >> 16), slot = (int)(e & 0xFFFFu);
+                // MODE 5 numbers candidates by their column in the table (spheres are tiled by position); everything
+                // the reference decides by a sphere's place in the list uses idx, the place in the caller's list
+                const int idx = TUBE ? (int)P.slot_orig[slot] : slot;
+                const double *__restrict__ pgeo = TUBE ? P.geo_slot : geo;
                 const int src = r << 2;
                 const D3 ro = mk(from_lane_f64(src, o.x), from_lane_f64(src, o.y), from_lane_f64(src, o.z));
                 const D3 rd = mk(from_lane_f64(src, d.x), from_lane_f64(src, d.y), from_lane_f64(src, d.z));
@@ -516,7 +532,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 if (act) {
                     if (DIAG) n_cand++;
                     // sphere.rs:16-34, exactly as exact_test() computes it
-                    const double4 g = *reinterpret_cast<const double4 *>(geo + 4 * (size_t)idx);
+                    const double4 g = *reinterpret_cast<const double4 *>(pgeo + 4 * (size_t)slot);
                     const double ra = length_squared(rd);
                     const D3 oc = ro - mk(g.x, g.y, g.z);
                     const double half_b = dot(oc, rd);
@@ -549,6 +565,8 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 pool_done = min(pool_done + 64u, pool_n);
             };
             // owners push the candidates of segment seg0 (ascending sphere order); rounds run as the ring fills
+            // MODE 5: the tiles this pass scans -- every tile of the table in turn, or the list in s_tlist
+            bool list_all = true;
             auto enumerate = [&](int seg0) {
                 unsigned summary = alive ? s_sum[tid] : 0u, word = 0u;
                 int wbase = 0;
@@ -561,7 +579,10 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                             const int w = __builtin_ctz(summary);
                             summary &= summary - 1u;
                             word = bits_w[w * 64 + lane];
-                            wbase = 16 * seg0 + 32 * w;
+                            if constexpr (TUBE)         // seg0: position in the tile list of the segment's first tile
+                                wbase = 32 * (list_all ? seg0 + w : (int)s_tlist[tid >> 6][seg0 + w]);
+                            else
+                                wbase = 16 * seg0 + 32 * w;
                         }
                         const int bpos = __builtin_ctz(word);
                         word &= word - 1u;
@@ -661,17 +682,105 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                         }
                     }
                 };
+                // ---- which tiles: the global ones and the grid cells some ray of the wave can reach ---------------
+                // Every ray finds the cells of its footprint (rt_device.hpp, grid_cells: columns ix0.., rows iz0..); the
+                // union over the wave becomes a list of tiles in LDS (tl[]: the global tiles, then the cells' tiles in
+                // ascending order, then two spare entries for the loop's look-ahead).  If a footprint cannot be
+                // computed, or the list is longer than kListCap, the wave scans every tile of the table instead.
+                int n_list = ntt;
+                unsigned int *tl = &s_tlist[wave][0];
+                auto wave_or = [](int v) -> int {               // the OR over the wave (DPP; lane 63 collects it)
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);    // row_shr:1
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);    // row_shr:2
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);    // row_shr:4
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);    // row_shr:8
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast15 -> rows 1, 3
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast31 -> rows 2, 3
+                    return __builtin_amdgcn_readlane(v, 63);
+                };
+                auto wave_scan_add = [](int v) -> int {         // inclusive prefix sum over the lanes (DPP)
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+                    return v;
+                };
+                if (P.grid_dim > 0) {
+                    int ix0 = 0, nx = 0, iz0 = 0, nz = 0, cnt = 0;
+                    RT_STAMP(5);
+                    if (scan && T.sane) cnt = grid_cells(o, d, P.grid, P.grid_dim, P.box_scale, ix0, nx, iz0, nz);
+                    RT_STAMP(7);
+                    const int gcells = P.grid_dim * P.grid_dim;
+                    if (P.n_global + gcells <= 64) {
+                        // a small grid: the cells fit ONE 64-bit mask per ray (bit iz * grid_dim + ix); the wave's set
+                        // of cells is the OR over its lanes, taken in registers, and lane c finds the place of cell c's
+                        // tile in the list by counting the set cells below it
+                        unsigned long long m = cnt < 0 ? ~0ull : 0ull;          // (cannot tell: every cell)
+                        if (cnt > 0) {
+                            // the footprint's columns, repeated in each of its rows: the rows sit grid_dim bits apart and
+                            // the run is narrower than that, so the product has no carries
+                            const unsigned long long run = (unsigned long long)(((1u << nx) - 1u) << ix0);
+                            const unsigned long long rows = P.grid_rows & (~0ull >> (64 - nz * P.grid_dim));
+                            m = (run * rows) << (iz0 * P.grid_dim);
+                        }
+                        const unsigned mlo = (unsigned)wave_or((int)(unsigned)m), mhi = (unsigned)wave_or((int)(unsigned)(m >> 32));
+                        const unsigned long long cells = (((unsigned long long)mhi << 32) | mlo) & (~0ull >> (64 - gcells));
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+                        tl[lane] = (unsigned)(lane < P.n_global ? lane : ntt);      // (past the list: the spare tile)
+                        if (lane < 2) tl[64 + lane] = (unsigned)ntt;
+                        __builtin_amdgcn_wave_barrier();
+                        if ((cells >> lane) & 1ull) tl[P.n_global + rank] = (unsigned)(P.n_global + lane);
+                        __builtin_amdgcn_wave_barrier();
+                        list_all = false;
+                        n_list = P.n_global + __builtin_popcountll(cells);
+                    } else if (__ballot(cnt < 0) == 0ull) {
+                        // a large grid: one 64-bit word per grid ROW in LDS, ORed by the rays; lane l then owns row l,
+                        // a prefix sum over the rows' cell counts gives each row its place in the list
+                        unsigned long long *tm = &s_tmask[wave][0];
+                        tm[lane] = 0ull;
+                        __builtin_amdgcn_wave_barrier();
+                        const unsigned long long run = ((1ull << nx) - 1ull) << ix0;    // nx + ix0 <= grid_dim <= 42
+                        if (cnt == 0) nz = 0;
+                        for (int k = 0; __any(k < nz); ++k)
+                            if (k < nz) atomicOr(&tm[iz0 + k], run);
+                        __builtin_amdgcn_wave_barrier();
+                        unsigned long long mw = tm[lane];
+                        const int mine = __builtin_popcountll(mw);
+                        const int upto = wave_scan_add(mine);
+                        const int tn = P.n_global + __builtin_amdgcn_readlane(upto, 63);
+                        if (tn <= kListCap) {
+                            if (lane < P.n_global) tl[lane] = (unsigned)lane;
+                            int pos = P.n_global + upto - mine;
+                            const int row0 = P.n_global + lane * P.grid_dim;
+                            while (__any(mw != 0ull)) {
+                                if (mw != 0ull) {
+                                    tl[pos++] = (unsigned)(row0 + __builtin_ctzll(mw));
+                                    mw &= mw - 1ull;
+                                }
+                            }
+                            if (lane < 2) tl[tn + lane] = (unsigned)ntt;
+                            __builtin_amdgcn_wave_barrier();
+                            list_all = false;
+                            n_list = tn;
+                        }
+                    }
+                }
+                RT_STAMP(3);
+                if (list_all && P.grid_dim > 0) RT_COUNT(2);
                 RT_STAMP(5);
                 // waves in the tile loop issue ahead of their SIMD partners: the matrix pipe is fed sooner and the other
                 // waves' vector work fills the time the MFMAs take (measured: -1.4 % on configs[1])
                 __builtin_amdgcn_s_setprio(1);
-                for (int seg0 = 0; seg0 < nt; seg0 += kSegTiles) {
-                    const int seg_n = min(kSegTiles, nt - seg0);
-                    const int nwords = seg_n >> 1;                  // one bitmap word per 32-sphere tile
+                for (int t0 = 0; t0 < n_list; t0 += kSegTiles / 2) {
+                    const int nwords = min(kSegTiles / 2, n_list - t0);     // one bitmap word per 32-sphere tile
                     for (int w = 0; w < nwords; ++w) bits_w[w * 64 + lane] = 0u;
                     s_sum[tid] = 0u;
+                    // the segment's tiles (and two more for the look-ahead), one per lane
+                    const int listv = list_all ? min(t0 + lane, ntt) : (int)tl[min(t0 + lane, kListCap + 1)];
+                    auto tile_at = [&](int j) -> int { return __builtin_amdgcn_readlane(listv, j); };      // j < 20, wave-uniform
                     __builtin_amdgcn_wave_barrier();
-                    const int t0 = seg0 >> 1;
                     // one 32-sphere tile: four independent MFMAs (one per 16-ray group); two results in
                     // flight so the matrix pipe works on the next group while the VALU looks at this one
                     auto do_tile = [&](int w, const bf16x8 &b) {
@@ -693,12 +802,12 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                     };
                     if (__builtin_expect(groups == 0xFu, 1)) {
                         // B operands ping-pong between two register sets, each fetched a tile ahead
-                        bf16x8 bp = load_b(t0), bq;
+                        bf16x8 bp = load_b(tile_at(0)), bq;
                         int w = 0;
                         for (; w + 1 < nwords; w += 2) {
-                            bq = load_b(t0 + w + 1);
+                            bq = load_b(tile_at(w + 1));
                             do_tile(w, bp);
-                            bp = load_b(t0 + w + 2);
+                            bp = load_b(tile_at(w + 2));
                             do_tile(w + 1, bq);
                         }
                         if (w < nwords) do_tile(w, bp);
@@ -707,7 +816,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                         // only the groups with one go through the matrix pipe and the look
                         for (int w = 0; w < nwords; ++w) {
                             RT_COUNT(7);
-                            const bf16x8 b = load_b(t0 + w);
+                            const bf16x8 b = load_b(tile_at(w));
 #pragma unroll
                             for (int G = 0; G < 4; ++G)
                                 if (groups & (1u << G)) {
@@ -719,8 +828,8 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                     __builtin_amdgcn_wave_barrier();
                     RT_STAMP(6);
                     __builtin_amdgcn_s_setprio(0);
-                    enumerate(seg0);
-                    if (seg0 + kSegTiles < nt) __builtin_amdgcn_s_setprio(1);
+                    enumerate(t0);
+                    if (t0 + kSegTiles / 2 < n_list) __builtin_amdgcn_s_setprio(1);
                 }
                 finish_pool();
                 }   // scan_mask != 0

@@ -6,11 +6,13 @@ import torch  # noqa
 from rtiow_amd import _ffi
 _ffi.LIB_PATH = os.environ["RTIOW_LIB"]
 import rtiow_amd as rt
-names = ["bounce-loop passes", "camera block", "lens retry trips", "keep path (half-looks with a hit)",
+names = ["bounce-loop passes", "camera block", "grid passes that scan every tile", "keep path (half-looks with a hit)",
          "keep path ray-group entries", "bitmap walk trips", "unit-sphere tries (wave level)", "tile iterations"]
 r = rt.Renderer(0)
-r.upload_scene(rt.random_scene(1).flatten())
-sm, fix, st = r.render(rt.book1_camera(1200, 675), rt.make_params(1200, 675, 100), want_fix=False)
+big = os.environ.get("SCENE") == "cfg4"
+r.upload_scene(rt.random_scene(1, grid=(-50, 49) if big else (-11, 11)).flatten())
+w, h, spp = (1920, 1080, 32) if big else (1200, 675, 100)
+sm, fix, st = r.render(rt.book1_camera(w, h), rt.make_params(w, h, spp), want_fix=False)
 out = (C.c_ulonglong * 8)()
 r._lib.rt_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 r._lib.rt_debug_phase_cycles(r._h, out)

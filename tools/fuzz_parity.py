@@ -15,13 +15,19 @@ tot_rays = 0
 for case in range(cases):
     rng = np.random.default_rng(seed0 * 100003 + case)
     n = int(rng.integers(1, 1200))
+    if rng.random() < 0.15:         # enough spheres for a grid of more than 64 cells (the kernel's second way of listing tiles)
+        n = int(rng.integers(1200, 5000))
     spread = float(10.0 ** rng.uniform(0.0, 3.0))
     w = rt.HittableList()
     if rng.random() < 0.6:
         w.push(rt.Sphere(rt.Point3(0, -1000 * spread / 10, 0), 1000 * spread / 10, rt.Lambertian(rt.Color(0.5, 0.5, 0.5))))
     rscale = spread / 10 * float(10.0 ** rng.uniform(-1.5, 0.3))
+    clusters = rng.uniform(-spread, spread, (int(rng.integers(1, 6)), 3)) if rng.random() < 0.25 else None
     for _ in range(n):
-        c = rng.uniform(-spread, spread, 3); c[1] = abs(c[1]) * rng.uniform(0.0, 0.5)
+        c = rng.uniform(-spread, spread, 3)
+        if clusters is not None and rng.random() < 0.85:     # dense clumps: grid cells overflow into the tiles every ray scans
+            c = clusters[rng.integers(0, len(clusters))] + rng.normal(size=3) * spread * 0.05
+        c[1] = abs(c[1]) * rng.uniform(0.0, 0.5)
         rad = float(rng.uniform(0.2, 1.5)) * rscale
         k = rng.integers(0, 3)
         m = (rt.Lambertian(rng.uniform(0.05, 0.95, 3)) if k == 0 else
