@@ -272,18 +272,23 @@ def main():
             import zlib
             frame_crc = zlib.crc32(step.last_full.cpu().numpy().tobytes()) & 0xFFFFFFFF
         roof = {
-            # What bounds the kernel is vector-instruction ISSUE: `issue` below.
-            # `achieved` is SURVEY.md 8(d)'s yardstick: the flop a brute-force scan would do for the rays
-            # traced (17 per ray-sphere pair + 65 per ray), NOT flop the kernel executes (the scan is a
-            # bf16 matrix-pipe filter + ~1 exact f64 test per ray).
-            "bound": "valu", "kernel": f"rt::render_kernel<{step.scan_mode}, false>",
-            "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4),
-            "achieved_is": "brute-force-equivalent flop (rays x (17 n_spheres + 65)) / kernel time",
+            # What bounds the kernel is vector-instruction ISSUE: `achieved` = vector (VALU)
+            # wave-instructions issued per second = the instruction count of one launch (SQ_INSTS_VALU, replayed: it is
+            # a property of kernel + configuration) / this run's kernel time; `frac` = the share of SIMD cycles in which
+            # a vector instruction is issuing (SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles), replayed); `peak` =
+            # achieved / frac: the rate this instruction mix would issue at with no idle SIMD cycle.
+            "bound": "valu-issue", "kernel": f"rt::render_kernel<{step.scan_mode}, false>",
+            "achieved": None, "peak": None, "unit": "G vector wave-instructions/s", "frac": None,
             "kernel_ms": round(k_ms, 3), "kernel_ms_source": "HIP events on the launch stream, this run",
             "launches_timed": len(kernel_ms),
-            "algorithmic_flop_per_launch": flops,
             "traffic": None, "issue": None, "mfma": None, "counters_source": pmc_note,
+            # SURVEY.md 8(d)'s yardstick, kept for comparison with round 1: the flop a BRUTE-FORCE f32 scan would do for
+            # the rays traced (17 per ray-sphere pair + 65 per ray) over this kernel's time.  It is not flop the kernel
+            # executes -- the scan is a bf16 matrix-pipe filter over the tiles a wave's rays can reach -- so it may
+            # exceed the FP32 vector peak: a speed-up over brute force, not a roofline.
+            "bruteforce_equivalent": {"TFLOPs": round(achieved, 3), "flop_per_launch": flops,
+                                      "fp32_vector_peak_TFLOPs": PEAK_FP32_VECTOR_TFLOPS,
+                                      "ratio_to_fp32_vector_peak": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4)},
             "hbm": {"algorithmic_bytes_per_launch": algo_bytes,
                     "achieved_GBps": round(algo_bytes / (k_ms * 1e-3) / 1e9, 4),
                     "peak_GBps": PEAK_HBM_GBPS,
@@ -293,9 +298,12 @@ def main():
             roof["traffic"] = pmc.get("hbm_bytes_per_launch")
             if pmc.get("rocprof_avg_kernel_ms"):
                 roof["kernel_ms_rocprof_avg"] = pmc["rocprof_avg_kernel_ms"]
-                roof["frac_rocprof_avg"] = round(flops / (pmc["rocprof_avg_kernel_ms"] * 1e-3) / 1e12 / PEAK_FP32_VECTOR_TFLOPS, 4)
             if pmc.get("valu_insts_per_launch") and pmc.get("simd_cycles_per_launch"):
                 wave_bounces = rays / 64.0
+                rate = pmc["valu_insts_per_launch"] / (k_ms * 1e-3) / 1e9
+                roof["achieved"] = round(rate, 1)
+                roof["frac"] = pmc.get("valu_busy")
+                roof["peak"] = round(rate / pmc["valu_busy"], 1) if pmc.get("valu_busy") else None
                 roof["issue"] = {
                     "valu_insts_per_launch": pmc["valu_insts_per_launch"],
                     "valu_insts_per_wave_bounce": round(pmc["valu_insts_per_launch"] / wave_bounces, 1),
