@@ -301,3 +301,44 @@ def test_extreme_aspect_ratios_and_tile_sizes(renderer, oracle_mod, book1_flat, 
             _, part, _ = renderer.render(cam, p)
             full[rt.shard_row_indices(p)] = part
         assert np.array_equal(full, fb)
+
+
+def _grid_scene(name):
+    """Scenes that put the position-tiled scan in its corners: a slab as thick as the scene, clumps whose
+    cells overflow into the global tiles, a line of spheres (no extent in z), a hundred spheres on one point, and a
+    scene of 3 000 spheres (a grid of more than 64 cells: the LDS form of the tile list)."""
+    rng = np.random.default_rng(23)
+    def sph(c, r):
+        flat = np.zeros(len(r), dtype=rt.SPHERE_DTYPE)
+        flat["center"], flat["radius"] = c, r
+        flat["kind"] = rng.integers(0, 3, len(r))
+        flat["albedo"] = rng.uniform(0.2, 0.9, (len(r), 3))
+        flat["param"] = np.where(flat["kind"] == 2, 1.5, rng.uniform(0.0, 0.4, len(r)))
+        return flat
+    if name == "cloud":
+        return sph(rng.uniform(-6, 6, (900, 3)), rng.uniform(0.1, 0.4, 900))
+    if name == "clusters":
+        c = np.concatenate([rng.normal((-3, 0.3, -2), 0.5, (300, 3)), rng.normal((3, 0.3, 1), 0.3, (250, 3)),
+                            rng.uniform(-8, 8, (150, 3)) * (1, 0.02, 1)])
+        return sph(c, rng.uniform(0.05, 0.2, len(c)))
+    if name == "line":
+        return sph(np.stack([np.linspace(-10, 10, 300), np.full(300, 0.2), np.zeros(300)], 1), np.where(np.arange(300) % 50 == 0, 1.5, 0.2))
+    if name == "same":
+        return sph(np.tile([[0.0, 0.5, 0.0]], (100, 1)), np.linspace(0.1, 0.6, 100))
+    if name == "many":
+        c = rng.uniform(-30, 30, (3000, 3)) * (1, 0.01, 1) + (0, 0.3, 0)
+        return sph(c, rng.uniform(0.1, 0.3, 3000))
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["cloud", "clusters", "line", "same", "many"])
+def test_position_tiled_scan_bit_exact_on_awkward_layouts(renderer, oracle_mod, name):
+    flat = _grid_scene(name)
+    for w, h, spp in [(48, 27, 3), (24, 13, 40)]:
+        (sm, fix, st), (fb, sb, stb), _ = both(renderer, oracle_mod, flat, w, h, spp)
+        assert np.array_equal(fix, fb), name
+        assert st["rays_traced"] == stb["rays_traced"]
+    # and the filter decides nothing here either
+    (sm2, fix2, st2), _, _ = both(renderer, oracle_mod, flat, 48, 27, 3, flags=rt.RT_FLAG_NO_FILTER)
+    (sm, fix, st), _, _ = both(renderer, oracle_mod, flat, 48, 27, 3)
+    assert np.array_equal(fix, fix2)
