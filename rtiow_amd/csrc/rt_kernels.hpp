@@ -567,8 +567,15 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
             // owners push the candidates of segment seg0 (ascending sphere order); rounds run as the ring fills
             // MODE 5: the tiles this pass scans -- every tile of the table in turn, or the list in s_tlist
             bool list_all = true;
-            auto enumerate = [&](int seg0) {
-                unsigned summary = alive ? s_sum[tid] : 0u, word = 0u;
+            auto enumerate = [&](int seg0, int nwords_tube = 0) {
+                unsigned summary = 0u, word = 0u;
+                if constexpr (TUBE) {
+                    // which of the segment's words hold a candidate of this ray (the recording side sets bits only)
+                    for (int w = 0; w < nwords_tube; ++w) summary |= bits_w[w * 64 + lane] != 0u ? 1u << w : 0u;
+                    if (!alive) summary = 0u;
+                } else {
+                    summary = alive ? s_sum[tid] : 0u;
+                }
                 int wbase = 0;
                 for (;;) {
                     const bool has = (summary | word) != 0u;
@@ -650,34 +657,29 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 // cycles at four waves per SIMD, v_or/v_bitop3 2.7-3.1): 58 instead of 81 cycles per MFMA + look.
                 auto keeps = [](uint32_t x) -> bool { return __builtin_fabsf(__uint_as_float(x)) < kTubeKeepBelow; };
                 auto look_tube = [&](int G, const f32x16 &acc, int wrel) {
-                    uint32_t X = __float_as_uint(acc[0]) | __float_as_uint(acc[4]);
+                    // X_bb: the AND over the four rays 8 bb + j of this lane; the wave-level branch tests X_0 & X_1
+                    uint32_t X[2];
 #pragma unroll
-                    for (int bb = 0; bb < 2; ++bb)
+                    for (int bb = 0; bb < 2; ++bb) {
+                        X[bb] = __float_as_uint(acc[8 * bb]) | __float_as_uint(acc[8 * bb + 4]);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (bb + j)
-                                X = __builtin_amdgcn_bitop3_b32(X, __float_as_uint(acc[8 * bb + j]), __float_as_uint(acc[8 * bb + 4 + j]), 0xE0);
-                    if (__builtin_expect(__ballot(keeps(X)) != 0ull, 0)) {
+                        for (int j = 1; j < 4; ++j)
+                            X[bb] = __builtin_amdgcn_bitop3_b32(X[bb], __float_as_uint(acc[8 * bb + j]), __float_as_uint(acc[8 * bb + 4 + j]), 0xE0);
+                    }
+                    if (__builtin_expect(__ballot(keeps(X[0] & X[1])) != 0ull, 0)) {
                         RT_COUNT(3);
                         int colv = col32;
                         asm volatile("" : "+v"(colv));              // keep the address arithmetic on this side of the branch
                         const unsigned bit = 1u << colv;
-                        const unsigned wbit = 1u << wrel;
                         unsigned int *row = bits_w + wrel * 64;
 #pragma unroll
                         for (int bb = 0; bb < 2; ++bb) {
-                            uint32_t p[4];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) p[j] = __float_as_uint(acc[8 * bb + j]) | __float_as_uint(acc[8 * bb + 4 + j]);
-                            if (__ballot(keeps((p[0] & p[1]) & (p[2] & p[3]))) != 0ull) {
+                            if (__ballot(keeps(X[bb])) != 0ull) {
                                 RT_COUNT(4);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j)
-                                    if (keeps(p[j])) {
-                                        const int ray = 16 * G + 8 * bb + 4 * hh + j;
-                                        atomicOr(&row[ray], bit);
-                                        atomicOr(&sum_w[ray], wbit);
-                                    }
+                                    if (keeps(__float_as_uint(acc[8 * bb + j]) | __float_as_uint(acc[8 * bb + 4 + j])))
+                                        atomicOr(&row[16 * G + 8 * bb + 4 * hh + j], bit);
                             }
                         }
                     }
@@ -776,7 +778,6 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 for (int t0 = 0; t0 < n_list; t0 += kSegTiles / 2) {
                     const int nwords = min(kSegTiles / 2, n_list - t0);     // one bitmap word per 32-sphere tile
                     for (int w = 0; w < nwords; ++w) bits_w[w * 64 + lane] = 0u;
-                    s_sum[tid] = 0u;
                     // the segment's tiles (and two more for the look-ahead), one per lane
                     const int listv = list_all ? min(t0 + lane, ntt) : (int)tl[min(t0 + lane, kListCap + 1)];
                     auto tile_at = [&](int j) -> int { return __builtin_amdgcn_readlane(listv, j); };      // j < 20, wave-uniform
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                     __builtin_amdgcn_wave_barrier();
                     RT_STAMP(6);
                     __builtin_amdgcn_s_setprio(0);
-                    enumerate(t0);
+                    enumerate(t0, nwords);
                     if (t0 + kSegTiles / 2 < n_list) __builtin_amdgcn_s_setprio(1);
                 }
                 finish_pool();
