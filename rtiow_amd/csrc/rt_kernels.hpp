@@ -102,6 +102,7 @@ constexpr int kRingMinSpp = 37;     //   ... which holds from 37 spp per launch 
 constexpr int kRingDepth = 4;       // blocks of one wave that may be unfinished at the same time (older ones: see `orphan`)
 constexpr int kMatStride = 10;      // doubles per material record
 constexpr int kListCap = 126;       // MODE 5: longest list of tiles a wave scans by list; beyond, it scans the whole table
+constexpr int kSegTilesTube = 28;   // MODE 5: 14 bitmap words of 32 columns per segment (a wave's list is 5-13 tiles long)
 constexpr int kSegTiles = 36;       // matrix filter: tiles (of 16 spheres) per candidate-bitmap segment
 
 __device__ __forceinline__ D3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
@@ -145,25 +146,33 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ~15 % of the frame time.
 template <int MODE, bool DIAG>
 // second launch bound = waves per SIMD the register allocator must leave room for: the bounce loop
-// is latency-bound, and the 4th wave is worth more than the few cold values it spills (the older
-// cross-check modes 2 and 3 keep their 10 KB ray-operand buffer: 3 workgroups per CU fit their LDS)
-__global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void render_kernel(const KParams P)
+// is latency-bound, and the 4th wave is worth more than the few cold values it spills.  Only the shipped kernel
+// (MODE 5 without the diagnostic counters) fits four workgroups' LDS on a CU (40 000 of 40 960 bytes each); the
+// diagnostic variant and the cross-check modes 2-4 carry 1-14 KB more and run three.
+__global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 : 5) void render_kernel(const KParams P)
 {
-    __shared__ uint16_t cand[MODE == 1 ? kCandCap : 1][kBlock];     // MODE 1: per-lane candidate lists
+    __shared__ uint16_t cand[MODE == 1 ? kCandCap : 1][MODE == 1 ? kBlock : 1];     // MODE 1: per-lane candidate lists
     constexpr bool MATRIX = (MODE >= 2);
     constexpr bool LIFTED = (MODE == 4);
     constexpr bool TUBE = (MODE == 5);
     constexpr bool RAYOP = (MODE == 2 || MODE == 3);
     __shared__ float s_rayop[RAYOP ? kBlock / 64 : 1][RAYOP ? 8 : 1][RAYOP ? kRowPad : 1];
-    // per ray, one bit per sphere of the current segment (kSegTiles tiles): set by whichever lane
-    // holds the passing result (ds_or, nothing returned, nothing waited for), read by the owner
-    // (MODE 4: the same LDS first carries the per-ray operand dwords to the MFMA layout)
-    static_assert((kSegTiles / 2) * 64 * sizeof(unsigned int) >= 32 * kStageStride * sizeof(uint4), "operand staging fits the bitmap");
-    static_assert((kSegTiles / 2) * 64 * sizeof(unsigned int) >= 64 * 4 * sizeof(uint4), "tube operand staging fits the bitmap");
-    __shared__ __attribute__((aligned(16))) unsigned int s_bits[MATRIX ? kBlock / 64 : 1][MATRIX ? kSegTiles / 2 : 1][MATRIX ? 64 : 1];
-    __shared__ unsigned long long s_tmask[TUBE ? kBlock / 64 : 1][TUBE ? 64 : 1];   // MODE 5: per wave and grid row, which cells its rays reach
-    __shared__ unsigned int s_tlist[TUBE ? kBlock / 64 : 1][TUBE ? kListCap + 2 : 1];   //   ... and the tiles of those cells
-    __shared__ unsigned int s_sum[MATRIX ? kBlock : 1];     // per ray: which of its bitmap words are non-zero
+    // per ray, one bit per sphere of the current segment (kSeg tiles of 16 columns): set by whichever lane
+    // holds the passing result (ds_or, nothing returned, nothing waited for), read by the owner.  The same LDS
+    // first carries the per-ray operand dwords to the MFMA layout (4 KB) and, for large grids, the wave's cell
+    // bitmap (512 B).
+    constexpr int kSeg = TUBE ? kSegTilesTube : kSegTiles;
+    static_assert(TUBE || (kSeg / 2) * 64 * sizeof(unsigned int) >= 32 * kStageStride * sizeof(uint4), "operand staging fits the bitmap");
+    // MODE 5: bitmap words (14 x 256 B) and the list of tiles this pass scans (128 x 4 B) share the 4 KB the staging
+    // needs before either exists
+    static_assert(!TUBE || ((kSeg / 2) * 64 + kListCap + 2) * sizeof(unsigned int) == 64 * 4 * sizeof(uint4), "tube: staging = bitmap + tile list");
+    constexpr int kBitWords = TUBE ? (kSeg / 2) * 64 + kListCap + 2 : (kSeg / 2) * 64;
+    __shared__ __attribute__((aligned(16))) unsigned int s_bits[MATRIX ? kBlock / 64 : 1][MATRIX ? kBitWords : 1];
+    __shared__ unsigned int s_sum[(MATRIX && !TUBE) ? kBlock : 1];     // per ray: which of its bitmap words are non-zero
+    // The wave's queue of started samples (below, (a)): the image-plane coordinates u, v (f64) and, as 32-bit columns,
+    // the two accepted lens words, pixel, sample and (events drawn << 8 | pixel slot of the block): 36 bytes per entry.
+    __shared__ double s_quv[kBlock / 64][2][64];
+    __shared__ unsigned int s_qid[kBlock / 64][5][64];
     // pooled exact tests: ring of waiting (ray << 16 | sphere) pairs per wave; per-ray minimum root and its sphere
     __shared__ unsigned int s_pool[MATRIX ? kBlock / 64 : 1][MATRIX ? 128 : 1];
     __shared__ unsigned long long s_best[MATRIX ? kBlock : 1];
@@ -205,7 +214,6 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
     bool dead = false, alive = false;
     uint32_t pix_local = 0, pix_global = 0;
     int s = 0;
-    uint32_t px_ij = 0;                            // pixel column | row << 16 (rt_params: both < 65536)
     uint32_t my_blk = 0;                           // sequence number (within this wave) of the block of this lane's sample << 4 | its pixel slot
     D3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     int depth = 0;
@@ -216,6 +224,10 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
     // its first item is sample blk_s0 of compact pixel blk_pix0 = row blk_rr0, column blk_i0 of the shard
     uint32_t blk_next = 0, blk_end = 0, blk_seq = 0xFFFFFFFFu, blk_pix0 = 0, blk_s0 = 0, blk_rr0 = 0, blk_i0 = 0;
     bool queue_empty = false;
+    // the wave's queue of camera rays: entries [q_head, q_head + q_count) of s_qray / s_qid (wave-uniform)
+    uint32_t q_head = 0, q_count = 0;
+    double *quv_w = &s_quv[tid >> 6][0][0];
+    unsigned int *qid_w = &s_qid[tid >> 6][0][0];
     unsigned long long *ring_w = &s_ring[tid >> 6][0][0];
     unsigned int *rpix_w = &s_rpix[tid >> 6][0];
     // samples the wave's four youngest blocks still wait for (wave-uniform; index = age: 0 is the current block
@@ -258,109 +270,135 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
 #endif
     for (;;) {
         RT_COUNT(0);
-        // ---- (a) idle lanes take the next pixel-samples of the wave's block ------------------
-        // A wave reserves kItemBlock consecutive items with ONE returning atomic on the
-        // device-wide counter and deals them to its lanes (ballot -> popcount -> prefix rank)
-        // until the block is used up: one word sustains only ~88 dequeues/us chip-wide
-        // (MI355X_MICROARCH.md, row "dequeue"), and a fetch per wave per bounce hit that wall.
+        // ---- (a) lanes without a path take the next camera rays of the wave's queue -------------------------
+        // Starting a sample (item -> pixel, Philox, lens rejection, the f64 camera arithmetic: ~340 vector
+        // instructions) used to run in every pass with only the ~38 % of lanes whose path had just ended.  Now the
+        // wave starts its next 64 items at once, with every lane busy -- everything up to the image-plane coordinates
+        // and the accepted lens sample -- parks them in LDS (36 bytes each) and hands them out over the next ~2.7
+        // passes: a lane that needs work takes entry head + its rank among the takers and builds its ray (camera.rs:47-54).  The queue is refilled only when it is empty, so its entries always belong to the
+        // wave's current block (blk_seq, blk_pix0).
         bool fresh = false;                                         // this lane starts a sample in this pass
+        double cam_u = 0.0, cam_v = 0.0;
+        uint32_t lens_wx = 0u, lens_wy = 0u;
         for (;;) {
             const bool want = !alive && !dead && !fresh;
             const unsigned long long m = __ballot(want);
             if (m == 0ull) break;
-            if (blk_next == blk_end) {                              // (wave-uniform) the block is used up: reserve the next one
-                uint32_t nb = 0xFFFFFFFFu;
-                if (!queue_empty) {
-                    const int leader = (int)__builtin_ctzll(m);
-                    if (lane == leader) nb = atomicAdd(P.queue, 1u);
-                    nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(nb, leader));
+            if (q_count == 0u) {
+                // ---- (b) refill: main.rs:131-134 + camera.rs:47-54 for the next (up to) 64 items of the block ----
+                // A wave reserves kItemBlock consecutive items with ONE returning atomic on the device-wide counter:
+                // one word sustains only ~88 dequeues/us chip-wide (MI355X_MICROARCH.md, row "dequeue").
+                if (blk_next == blk_end) {                          // (wave-uniform) the block is used up: reserve the next one
+                    uint32_t nb = 0xFFFFFFFFu;
+                    if (!queue_empty) {
+                        const int leader = (int)__builtin_ctzll(m);
+                        if (lane == leader) nb = atomicAdd(P.queue, 1u);
+                        nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(nb, leader));
+                    }
+                    if (nb >= P.n_blocks) {                         // no work left anywhere: these lanes are done
+                        queue_empty = true;
+                        if (want) dead = true;
+                        break;
+                    }
+                    // first item of the block -> (pixel, sample): W0 / spp in f64 (W0 < 2^39: exact), one correction step
+                    const unsigned long long W0 = (unsigned long long)nb * (unsigned long long)kItemBlock;
+                    const unsigned long long left = P.total_items - W0;
+                    const uint32_t n_items = left < (unsigned long long)kItemBlock ? (uint32_t)left : (uint32_t)kItemBlock;
+                    uint32_t p0 = (uint32_t)((double)W0 * P.inv_spp);
+                    long long rem = (long long)(W0 - (unsigned long long)p0 * (unsigned long long)(uint32_t)P.spp);
+                    if (rem < 0) { p0 -= 1u; rem += (long long)P.spp; }
+                    else if (rem >= (long long)P.spp) { p0 += 1u; rem -= (long long)P.spp; }
+                    blk_pix0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);
+                    blk_s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rem);
+                    uint32_t rr0 = (uint32_t)((double)blk_pix0 * P.inv_width);     // pixel / width the same way
+                    int i0 = (int)(blk_pix0 - rr0 * (uint32_t)P.width);
+                    if (i0 < 0) { rr0 -= 1u; i0 += P.width; } else if (i0 >= P.width) { rr0 += 1u; i0 -= P.width; }
+                    blk_rr0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rr0);                  // (keeps them in SGPRs)
+                    blk_i0 = (uint32_t)__builtin_amdgcn_readfirstlane(i0);
+                    blk_next = 0u; blk_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_items);
+                    blk_seq += 1u;
+                    if (P.use_ring) {
+                        // The oldest of the four blocks leaves the ring.  If a path of > ~30 bounces still holds it open,
+                        // what it has collected goes out now and its remaining samples will go to the frame buffer
+                        // directly when they finish ("orphans": their age is then >= kRingDepth).
+                        if (rem3 != 0u) flush_ring(blk_seq & (uint32_t)(kRingDepth - 1));
+                        rem3 = rem2; rem2 = rem1; rem1 = rem0; rem0 = blk_end;
+                        if (lane == 0) rpix_w[blk_seq & (uint32_t)(kRingDepth - 1)] = blk_pix0;
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
-                if (nb >= P.n_blocks) {                             // no work left anywhere: these lanes are done
-                    queue_empty = true;
-                    if (want) dead = true;
-                    break;
+                const uint32_t n_gen = min(64u, blk_end - blk_next);
+                RT_COUNT(1);
+                if ((uint32_t)lane < n_gen) {
+                    // item blk_next + lane of the block: sample blk_s0 + that of pixel blk_pix0, carried over into the next pixels
+                    const uint32_t s_rel = blk_s0 + blk_next + (uint32_t)lane;
+                    const uint32_t dq = udiv_small(s_rel, (uint32_t)P.spp, P.magic_spp);   // pixel slot within the block (< kRingSlots when use_ring)
+                    const uint32_t col = blk_i0 + dq;
+                    const uint32_t rq = udiv_small(col, (uint32_t)P.width, P.magic_width);
+                    const uint32_t i = col - rq * (uint32_t)P.width;
+                    const uint32_t rr = blk_rr0 + rq;
+                    const uint32_t lt = udiv_small(rr, (uint32_t)P.tile_rows, P.magic_tile);   // local tile
+                    const uint32_t j = (lt * (uint32_t)P.shard_count + (uint32_t)P.shard_index) * (uint32_t)P.tile_rows
+                                       + (rr - lt * (uint32_t)P.tile_rows);
+                    const uint32_t g_pix = j * (uint32_t)P.width + i;
+                    const uint32_t g_s = (uint32_t)P.sample_begin + (s_rel - dq * (uint32_t)P.spp);
+                    U4 w = philox4x32_10(g_pix, g_s, 0u, 0u, P.k0, P.k1);
+                    uint32_t g_ev = 1u;
+                    const double u = ((double)i + u01(w.x)) / wm1;                   // main.rs:131
+                    const double v = ((double)j + u01(w.y)) / hm1;                   // main.rs:132
+                    // vec3.rs:59-68: redraw until x*x + y*y < 1.  x = u11(w) = m * 2^-23 with the integer m = (w >> 8) - 2^23, and
+                    // the f64 sum of squares of such values is EXACT (47 bits), so the reference's f64 comparison is the integer
+                    // comparison m_x^2 + m_y^2 < 2^46: the loop runs on integers, the accepted pair is converted once.
+                    // Block 0 = (u jitter, v jitter, lens x, lens y); every further block holds TWO tries.
+                    uint32_t wx = w.z, wy = w.w;
+                    while (!unit_disk_accepts(wx, wy)) {
+                        w = philox4x32_10(g_pix, g_s, g_ev, 0u, P.k0, P.k1);
+                        g_ev++;
+                        wx = w.x; wy = w.y;
+                        if (!unit_disk_accepts(wx, wy)) { wx = w.z; wy = w.w; }
+                    }
+                    quv_w[0 * 64 + lane] = u;
+                    quv_w[1 * 64 + lane] = v;
+                    qid_w[0 * 64 + lane] = wx;
+                    qid_w[1 * 64 + lane] = wy;
+                    qid_w[2 * 64 + lane] = g_pix;
+                    qid_w[3 * 64 + lane] = g_s;
+                    qid_w[4 * 64 + lane] = (g_ev << 8) | dq;        // (the event counter has 24 bits here: 8 million lens retries)
                 }
-                // first item of the block -> (pixel, sample): W0 / spp in f64 (W0 < 2^39: exact), one correction step
-                const unsigned long long W0 = (unsigned long long)nb * (unsigned long long)kItemBlock;
-                const unsigned long long left = P.total_items - W0;
-                const uint32_t n_items = left < (unsigned long long)kItemBlock ? (uint32_t)left : (uint32_t)kItemBlock;
-                uint32_t p0 = (uint32_t)((double)W0 * P.inv_spp);
-                long long rem = (long long)(W0 - (unsigned long long)p0 * (unsigned long long)(uint32_t)P.spp);
-                if (rem < 0) { p0 -= 1u; rem += (long long)P.spp; }
-                else if (rem >= (long long)P.spp) { p0 += 1u; rem -= (long long)P.spp; }
-                blk_pix0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);
-                blk_s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rem);
-                uint32_t rr0 = (uint32_t)((double)blk_pix0 * P.inv_width);     // pixel / width the same way
-                int i0 = (int)(blk_pix0 - rr0 * (uint32_t)P.width);
-                if (i0 < 0) { rr0 -= 1u; i0 += P.width; } else if (i0 >= P.width) { rr0 += 1u; i0 -= P.width; }
-                blk_rr0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rr0);                  // (keeps them in SGPRs)
-                blk_i0 = (uint32_t)__builtin_amdgcn_readfirstlane(i0);
-                blk_next = 0u; blk_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_items);
-                blk_seq += 1u;
-                if (P.use_ring) {
-                    // The oldest of the four blocks leaves the ring.  If a path of > ~30 bounces still holds it open,
-                    // what it has collected goes out now and its remaining samples will go to the frame buffer
-                    // directly when they finish ("orphans": their age is then >= kRingDepth).
-                    if (rem3 != 0u) flush_ring(blk_seq & (uint32_t)(kRingDepth - 1));
-                    rem3 = rem2; rem2 = rem1; rem1 = rem0; rem0 = blk_end;
-                    if (lane == 0) rpix_w[blk_seq & (uint32_t)(kRingDepth - 1)] = blk_pix0;
-                    __builtin_amdgcn_wave_barrier();
-                }
+                blk_next += n_gen;
+                q_head = 0u; q_count = n_gen;
+                __builtin_amdgcn_wave_barrier();
             }
-            const uint32_t avail = blk_end - blk_next;
             const uint32_t r = rank_below(m);
-            if (want && r < avail) {
-                // item blk_next + r of the block: sample blk_s0 + that of pixel blk_pix0, carried over into the next pixels
-                const uint32_t s_rel = blk_s0 + blk_next + r;
-                const uint32_t dq = udiv_small(s_rel, (uint32_t)P.spp, P.magic_spp);   // pixel slot within the block (< kRingSlots when use_ring)
-                const uint32_t col = blk_i0 + dq;
-                const uint32_t rq = udiv_small(col, (uint32_t)P.width, P.magic_width);
-                const uint32_t i = col - rq * (uint32_t)P.width;
-                const uint32_t rr = blk_rr0 + rq;
-                const uint32_t lt = udiv_small(rr, (uint32_t)P.tile_rows, P.magic_tile);   // local tile
-                const uint32_t j = (lt * (uint32_t)P.shard_count + (uint32_t)P.shard_index) * (uint32_t)P.tile_rows
-                                   + (rr - lt * (uint32_t)P.tile_rows);
-                pix_local = blk_pix0 + dq;
-                pix_global = j * (uint32_t)P.width + i;
-                px_ij = i | (j << 16);
-                s = P.sample_begin + (int)(s_rel - dq * (uint32_t)P.spp);
-                my_blk = (blk_seq << 4) | dq;
+            if (want && r < q_count) {
+                const uint32_t e = q_head + r;
+                cam_u = quv_w[0 * 64 + e]; cam_v = quv_w[1 * 64 + e];
+                lens_wx = qid_w[0 * 64 + e]; lens_wy = qid_w[1 * 64 + e];
+                pix_global = qid_w[2 * 64 + e];
+                s = (int)qid_w[3 * 64 + e];
+                const uint32_t meta = qid_w[4 * 64 + e];
+                ev = meta >> 8;
+                pix_local = blk_pix0 + (meta & 255u);
+                my_blk = (blk_seq << 4) | (meta & 15u);
                 fresh = true;
             }
             const uint32_t cnt = (uint32_t)__popcll(m);
-            blk_next += cnt < avail ? cnt : avail;
+            const uint32_t took = cnt < q_count ? cnt : q_count;
+            q_head += took; q_count -= took;
         }
-
-        RT_STAMP(0);
-        // ---- (b) start the sample: main.rs:131-134 + camera.rs:47-54 ----
-        if (fresh) {
-            RT_COUNT(1);
-            U4 w = philox4x32_10(pix_global, (uint32_t)s, 0u, 0u, P.k0, P.k1);
-            ev = 1u;
-            const double u = ((double)(px_ij & 0xFFFFu) + u01(w.x)) / wm1;   // main.rs:131
-            const double v = ((double)(px_ij >> 16) + u01(w.y)) / hm1;       // main.rs:132
-            // vec3.rs:59-68: redraw until x*x + y*y < 1.  x = u11(w) = m * 2^-23 with the integer m = (w >> 8) - 2^23, and
-            // the f64 sum of squares of such values is EXACT (47 bits), so the reference's f64 comparison is the integer
-            // comparison m_x^2 + m_y^2 < 2^46: the loop runs on integers, the accepted pair is converted once.
-            // Block 0 = (u jitter, v jitter, lens x, lens y); every further block holds TWO tries.
-            uint32_t wx = w.z, wy = w.w;
-            while (!unit_disk_accepts(wx, wy)) {
-                w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
-                ev++;
-                wx = w.x; wy = w.y;
-                if (!unit_disk_accepts(wx, wy)) { wx = w.z; wy = w.w; }
-            }
-            const double lx = u11(wx), ly = u11(wy);
+        if (fresh) {                                                // camera.rs:47-54
+            const double lx = u11(lens_wx), ly = u11(lens_wy);
             const D3 cam_origin = ld3(P.cam.origin);
             const D3 rd = mk(lx, ly, 0.0) * P.cam.lens_radius;
             const D3 offset = ld3(P.cam.u) * rd.x + ld3(P.cam.v) * rd.y;
             o = cam_origin + offset;
-            d = (((ld3(P.cam.llc) + ld3(P.cam.horizontal) * u) + ld3(P.cam.vertical) * v) - cam_origin) - offset;
+            d = (((ld3(P.cam.llc) + ld3(P.cam.horizontal) * cam_u) + ld3(P.cam.vertical) * cam_v) - cam_origin) - offset;
             s_thr[0][tid] = 1.0; s_thr[1][tid] = 1.0; s_thr[2][tid] = 1.0;
             depth = P.max_depth;
             alive = true;
         }
 
+        RT_STAMP(0);
         RT_STAMP(1);
         // ---- (c) every lane of the wave is out of work: done ------------------
         const unsigned long long alive_mask = __ballot(alive);
@@ -416,8 +454,8 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
             const int wave = tid >> 6;
             const int col = lane & 15, quad = lane >> 4;
             const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-            unsigned int *bits_w = &s_bits[wave][0][0];             // [word][ray]
-            unsigned int *sum_w = &s_sum[wave * 64];
+            unsigned int *bits_w = &s_bits[wave][0];                // [word][ray]
+            unsigned int *sum_w = &s_sum[TUBE ? 0 : wave * 64];         // (MODE 5 has no summary words)
 #ifdef RTIOW_CROSSCHECK_MODES
             // Results of half a tile: Dv[g][i] belongs to ray 16(2h+g) + 4 quad + i and sphere
             // 16 t + col; it is kept iff Dv >= kp.  Hits are rare, so the eight values are first
@@ -565,7 +603,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 pool_done = min(pool_done + 64u, pool_n);
             };
             // owners push the candidates of segment seg0 (ascending sphere order); rounds run as the ring fills
-            // MODE 5: the tiles this pass scans -- every tile of the table in turn, or the list in s_tlist
+            // MODE 5: the tiles this pass scans -- every tile of the table in turn, or the list behind the bitmap words
             bool list_all = true;
             auto enumerate = [&](int seg0, int nwords_tube = 0) {
                 unsigned summary = 0u, word = 0u;
@@ -587,7 +625,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                             summary &= summary - 1u;
                             word = bits_w[w * 64 + lane];
                             if constexpr (TUBE)         // seg0: position in the tile list of the segment's first tile
-                                wbase = 32 * (list_all ? seg0 + w : (int)s_tlist[tid >> 6][seg0 + w]);
+                                wbase = 32 * (list_all ? seg0 + w : (int)bits_w[(kSeg / 2) * 64 + seg0 + w]);
                             else
                                 wbase = 16 * seg0 + 32 * w;
                         }
@@ -690,7 +728,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 // ascending order, then two spare entries for the loop's look-ahead).  If a footprint cannot be
                 // computed, or the list is longer than kListCap, the wave scans every tile of the table instead.
                 int n_list = ntt;
-                unsigned int *tl = &s_tlist[wave][0];
+                unsigned int *tl = bits_w + (kSeg / 2) * 64;                // (behind the bitmap words)
                 auto wave_or = [](int v) -> int {               // the OR over the wave (DPP; lane 63 collects it)
                     v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);    // row_shr:1
                     v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);    // row_shr:2
@@ -740,7 +778,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                     } else if (__ballot(cnt < 0) == 0ull) {
                         // a large grid: one 64-bit word per grid ROW in LDS, ORed by the rays; lane l then owns row l,
                         // a prefix sum over the rows' cell counts gives each row its place in the list
-                        unsigned long long *tm = &s_tmask[wave][0];
+                        unsigned long long *tm = reinterpret_cast<unsigned long long *>(bits_w);   // (512 B of the bitmap area, free until the tile loop)
                         tm[lane] = 0ull;
                         __builtin_amdgcn_wave_barrier();
                         const unsigned long long run = ((1ull << nx) - 1ull) << ix0;    // nx + ix0 <= grid_dim <= 42
@@ -775,8 +813,8 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                 // waves in the tile loop issue ahead of their SIMD partners: the matrix pipe is fed sooner and the other
                 // waves' vector work fills the time the MFMAs take (measured: -1.4 % on configs[1])
                 __builtin_amdgcn_s_setprio(1);
-                for (int t0 = 0; t0 < n_list; t0 += kSegTiles / 2) {
-                    const int nwords = min(kSegTiles / 2, n_list - t0);     // one bitmap word per 32-sphere tile
+                for (int t0 = 0; t0 < n_list; t0 += kSeg / 2) {
+                    const int nwords = min(kSeg / 2, n_list - t0);          // one bitmap word per 32-sphere tile
                     for (int w = 0; w < nwords; ++w) bits_w[w * 64 + lane] = 0u;
                     // the segment's tiles (and two more for the look-ahead), one per lane
                     const int listv = list_all ? min(t0 + lane, ntt) : (int)tl[min(t0 + lane, kListCap + 1)];
@@ -830,7 +868,7 @@ __global__ __launch_bounds__(kBlock, (MODE >= 4) ? 4 : (MODE >= 2) ? 3 : 5) void
                     RT_STAMP(6);
                     __builtin_amdgcn_s_setprio(0);
                     enumerate(t0, nwords);
-                    if (t0 + kSegTiles / 2 < n_list) __builtin_amdgcn_s_setprio(1);
+                    if (t0 + kSeg / 2 < n_list) __builtin_amdgcn_s_setprio(1);
                 }
                 finish_pool();
                 }   // scan_mask != 0

@@ -1,0 +1,8 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["RTIOW_HIP_LIB"] = sys.argv[1]
+import rtiow_amd as rt
+r = rt.Renderer(0); r.upload_scene(rt.random_scene(1).flatten())
+_, _, st = r.render(rt.book1_camera(1200, 675), rt.make_params(1200, 675, 100), want_fix=False)
+_, _, st = r.render(rt.book1_camera(1200, 675), rt.make_params(1200, 675, 100), want_fix=False)
+print(sys.argv[1], st["grid_blocks"], st["kernel_ms"])
