@@ -342,3 +342,30 @@ def test_position_tiled_scan_bit_exact_on_awkward_layouts(renderer, oracle_mod, 
     (sm2, fix2, st2), _, _ = both(renderer, oracle_mod, flat, 48, 27, 3, flags=rt.RT_FLAG_NO_FILTER)
     (sm, fix, st), _, _ = both(renderer, oracle_mod, flat, 48, 27, 3)
     assert np.array_equal(fix, fix2)
+
+
+@pytest.mark.parametrize("scale,cam_far,t_min", [(1e11, 2e4, 1e-4), (1e-13, 1.0, 1e-17)])
+def test_rays_and_scenes_outside_the_filters_analysed_range(renderer, oracle_mod, scale, cam_far, t_min):
+    """A camera 2.7e16 away from a scene of size 1e12 (|o| >= 1e15: the f32 filter and the grid footprint both answer
+    "cannot tell" for the camera rays, which then test every sphere exactly while their wave scans every tile; the
+    bounce rays are back inside the range), and a scene of size 1e-12 (radii squared below 1e-30, directions squared
+    below 1e-20): the same bits as the oracle."""
+    rng = np.random.default_rng(5)
+    n = 150
+    flat = np.zeros(n + 1, dtype=rt.SPHERE_DTYPE)
+    flat["center"][0], flat["radius"][0] = (0.0, -1000.0 * scale, 0.0), 1000.0 * scale
+    flat["center"][1:] = rng.uniform(-8, 8, (n, 3)) * (1, 0.0, 1) * scale + (0, 0.3 * scale, 0)
+    flat["radius"][1:] = rng.uniform(0.1, 0.3, n) * scale
+    flat["kind"] = rng.integers(0, 3, n + 1)
+    flat["kind"][0] = 0
+    flat["albedo"] = rng.uniform(0.3, 0.9, (n + 1, 3))
+    flat["param"] = np.where(flat["kind"] == 2, 1.5, 0.2)
+    renderer.upload_scene(flat)
+    w, h, spp = 40, 24, 3
+    far = scale * cam_far
+    cam = rt.Camera(rt.Point3(13 * far, 2 * far, 3 * far), rt.Point3(0, 0, 0), rt.Vec3(0, 1, 0), 25.0 / cam_far, w / h, 0.1 * scale, float(np.sqrt(182.0)) * far)
+    # (t_min is a ray PARAMETER: camera rays have |d| of the camera's distance, scattered rays |d| of order 1)
+    sm, fix, st = renderer.render(cam, rt.make_params(w, h, spp, t_min=t_min))
+    fb, sb, stb = oracle_mod.render_b(oracle_mod.camera_from_host(cam), flat, oracle_mod.make_params(w, h, spp, t_min=t_min))
+    assert np.array_equal(fix, fb)
+    assert st["rays_traced"] == stb["rays_traced"] and st["rays_traced"] > 1.5 * w * h * spp     # (the scene is hit)
