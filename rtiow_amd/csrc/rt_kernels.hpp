@@ -9,9 +9,10 @@
 //     regeneration"), so the sphere scan always runs with full waves;
 //   * work = single pixel-samples in PIXEL-MAJOR order (item w = pixel * spp + sample); a wave
 //     reserves a block of kItemBlock consecutive items with ONE returning atomic on a device-wide
-//     counter and deals them to its idle lanes (__ballot + popcount + v_mbcnt rank); a block is
-//     at most 8 neighbouring pixels, so its 64-lane wave traces coherent camera rays and the
-//     launch ends on single samples;
+//     counter, STARTS them 64 at a time (item -> pixel, Philox, lens sample: every lane busy) into a
+//     per-wave LDS queue and deals the started samples to the lanes whose paths end (__ballot +
+//     popcount + v_mbcnt rank); a block is at most 8 neighbouring pixels, so its 64-lane wave traces
+//     coherent camera rays and the launch ends on single samples;
 //   * the sphere scan (HittableList::hit, mod.rs:54-70) decides nothing: it is a
 //     conservative FILTER (rt_device.hpp) -- it may send a sphere to the exact
 //     test needlessly, never drop one the reference would hit.  The shipped form
