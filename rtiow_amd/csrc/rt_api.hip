@@ -59,9 +59,7 @@ struct rt_context {
     int n_global = 0;              // MODE 5: tiles [0, n_global) are scanned for every ray; the rest are grid cells
     int grid_dim = 0;              // MODE 5: cells per side of the xz grid (0: no grid, every tile is scanned)
     float grid[8] = {};            // x0, z0, 1/cell, x1, z1, y lo, y hi, pad (rt_device.hpp, mark_grid_cells)
-    float boxes[rt::kMaxBoxes][6] = {};   // MODE 5: boxes that hold every scanned sphere (lo xyz, hi xyz)
-    float box_scale = 0.0f;
-    int n_boxes = 0;
+    float scene_scale = 0.0f;      // MODE 5: KParams::scene_scale
 #ifdef RTIOW_CROSSCHECK_MODES
     float *d_bmat = nullptr;       // [tiles][64] MFMA B operand of the filter
     float *d_kpt = nullptr;        // [tiles][16] K' per sphere
@@ -435,7 +433,7 @@ TileLayout tile_layout(const rt_sphere *spheres, int n, const char *never)
             L.grid[2] = (float)(1.0 / cell);
             L.grid[3] = up(x0 + G * cell); L.grid[4] = up(z0 + G * cell);
             L.grid[5] = down(ylo); L.grid[6] = up(yhi); L.grid[7] = up(pad);
-            // the kernel's error margins are relative to the size of what a ray can reach: the boxes and the grid
+            // the kernel's error margins are relative to the size of what a ray can reach inside the grid's box
             const double gs = std::max(std::fabs(x0), std::fabs(x0 + G * cell)) + pad + std::max(std::fabs(ylo), std::fabs(yhi)) +
                               std::max(std::fabs(z0), std::fabs(z0 + G * cell)) + pad;
             L.scale = (float)gs * 1.0001f;
@@ -575,61 +573,12 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
         std::vector<char> never(n > 0 ? n : 1, 0);
         for (int e = 0; e < ctx->n_always; ++e) never[ctx->always_idx[e]] = 1;
         ctx->tube_rho = tube_radius_floor(spheres, n, never.data());
-        // Bounding boxes of the scanned spheres (rt_device.hpp, ray_may_reach_boxes), rounded outwards: the
-        // (up to 3) spheres more than 3x the median radius of the scanned ones get a box each -- they would
-        // otherwise make the common box as tall as themselves -- and the rest share one.
-        {
-            std::vector<int> idx;
-            for (int i = 0; i < n; ++i) if (!never[i]) idx.push_back(i);
-            std::vector<double> rr;
-            for (int i : idx) rr.push_back(std::fabs(spheres[i].radius));
-            double med = 0.0;
-            if (!rr.empty()) { std::nth_element(rr.begin(), rr.begin() + rr.size() / 2, rr.end()); med = rr[rr.size() / 2]; }
-            std::vector<int> big;
-            for (int i : idx) if (std::fabs(spheres[i].radius) > 3.0 * med) big.push_back(i);
-            std::sort(big.begin(), big.end(), [&](int x, int y) { return std::fabs(spheres[x].radius) > std::fabs(spheres[y].radius); });
-            if (big.size() > (size_t)rt::kMaxBoxes - 1) big.resize(rt::kMaxBoxes - 1);
-            std::vector<char> own(n > 0 ? n : 1, 0);
-            for (int i : big) own[i] = 1;
-            ctx->n_boxes = 0;
-            ctx->box_scale = 0.0f;
-            double scale[3] = {0.0, 0.0, 0.0};
-            auto add_box = [&](const double lo[3], const double hi[3]) {
-                float *bx = ctx->boxes[ctx->n_boxes++];
-                for (int k = 0; k < 3; ++k) {
-                    float fl = (float)lo[k], fh = (float)hi[k];
-                    if ((double)fl > lo[k]) fl = std::nextafterf(fl, -INFINITY);
-                    if ((double)fh < hi[k]) fh = std::nextafterf(fh, INFINITY);
-                    bx[k] = fl; bx[3 + k] = fh;
-                    scale[k] = std::max(scale[k], (double)std::max(std::fabs(fl), std::fabs(fh)));
-                }
-            };
-            for (int i : big) {
-                const double r = std::fabs(spheres[i].radius);
-                const double lo[3] = {spheres[i].center[0] - r, spheres[i].center[1] - r, spheres[i].center[2] - r};
-                const double hi[3] = {spheres[i].center[0] + r, spheres[i].center[1] + r, spheres[i].center[2] + r};
-                add_box(lo, hi);
-            }
-            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-            bool any_rest = false;
-            for (int i : idx) {
-                if (own[i]) continue;
-                any_rest = true;
-                const double r = std::fabs(spheres[i].radius);
-                for (int k = 0; k < 3; ++k) {
-                    lo[k] = std::min(lo[k], spheres[i].center[k] - r);
-                    hi[k] = std::max(hi[k], spheres[i].center[k] + r);
-                }
-            }
-            if (any_rest) add_box(lo, hi);
-            ctx->box_scale = (float)(scale[0] + scale[1] + scale[2]) * 1.0001f;
-        }
         // which column of the table holds which sphere, and the grid the kernel finds tiles with
         const TileLayout L = tile_layout(spheres, n, never.data());
         const std::vector<int> &slot_of = L.slot_of;
         ctx->grid_dim = L.grid_dim; ctx->n_global = L.n_global;
         for (int k = 0; k < 8; ++k) ctx->grid[k] = L.grid[k];
-        ctx->box_scale = std::max(ctx->box_scale, L.scale);
+        ctx->scene_scale = L.scale;
         const int n_tiles32 = (int)(slot_of.size() / 32);
         ctx->n_tiles = 2 * n_tiles32;                          // (counted in 16-column units, as the other scan modes do)
         const size_t ttc = (size_t)n_tiles32 + 1;              // one spare tile: the pipelined loop never branches on a table bound
@@ -794,9 +743,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.grid_rows = 0ull;
     for (int k = 0; ctx->grid_dim > 0 && (k + 1) * ctx->grid_dim <= 64; ++k) kp.grid_rows |= 1ull << (k * ctx->grid_dim);
     for (int k = 0; k < 8; ++k) kp.grid[k] = ctx->grid[k];
-    memcpy(kp.boxes, ctx->boxes, sizeof(kp.boxes));
-    kp.box_scale = ctx->box_scale;
-    kp.n_boxes = env_int("RTIOW_NO_BOX_CULL", 0) ? -1 : ctx->n_boxes;      // (diagnostic A/B: -1 = never cull)
+    kp.scene_scale = ctx->scene_scale;
     kp.n_always = ctx->n_always;
     for (int e = 0; e < 8; ++e) kp.always_idx[e] = ctx->always_idx[e];
     kp.fix = (unsigned long long *)d_fix;

@@ -358,40 +358,6 @@ constexpr float kTubeBasisErr = 64.0f * kUnitRoundoff;
 constexpr float kTubeCenterErr = 640.0f * kUnitRoundoff;
 constexpr float kTubeOriginErr = 128.0f * kUnitRoundoff;
 
-// Can the ray o + t d, t > 0, come within reach of one of n axis-aligned boxes (box[k] = lo xyz, hi xyz; together
-// they hold every scanned sphere; host: rounded outwards)?  Slab tests in f32, biased to answer "yes":
-//   * o and d are rounded to f32 (6e-8 relative each): the line they define stays within 6e-8 (|o| + L) of the true
-//     one at distance L, and a box can only matter for L <= |o| + the scene's size, so every box is grown by
-//     e = 1e-6 (|o|_1 + scale) on every side;
-//   * v_rcp_f32 and the products put <= 3e-7 relative error on each slab parameter: the interval test keeps a
-//     ray unless the exit parameter lies below 0.9999 of the entry parameter;
-//   * a direction component of magnitude < 1e-30, a non-finite value or |o|, |d| beyond 1e15: always "yes"
-//     (a NaN anywhere makes the final comparison false, which also answers "yes").
-constexpr int kMaxBoxes = 4;
-__device__ __forceinline__ bool ray_may_reach_boxes(D3 o, D3 d, const float (&box)[kMaxBoxes][6], int n, float scale)
-{
-    const float of[3] = {(float)o.x, (float)o.y, (float)o.z};
-    const float df[3] = {(float)d.x, (float)d.y, (float)d.z};
-    const float o1 = __builtin_fabsf(of[0]) + __builtin_fabsf(of[1]) + __builtin_fabsf(of[2]);
-    const float e = 1e-6f * (o1 + scale);
-    const float inv[3] = {__builtin_amdgcn_rcpf(df[0]), __builtin_amdgcn_rcpf(df[1]), __builtin_amdgcn_rcpf(df[2])};
-    const float dmin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(df[0]), __builtin_fabsf(df[1])), __builtin_fabsf(df[2]));
-    const float dmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(df[0]), __builtin_fabsf(df[1])), __builtin_fabsf(df[2]));
-    const bool sane = dmin > 1e-30f && dmax < 1e15f && o1 < 1e15f;
-    bool any = !sane;
-    for (int k = 0; k < n; ++k) {                       // n is wave-uniform
-        float t_in = 0.0f, t_out = __builtin_inff();
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float t0 = ((box[k][a] - e) - of[a]) * inv[a], t1 = ((box[k][3 + a] + e) - of[a]) * inv[a];
-            t_in = __builtin_fmaxf(t_in, __builtin_fminf(t0, t1));
-            t_out = __builtin_fminf(t_out, __builtin_fmaxf(t0, t1));
-        }
-        any = any || !(t_out < t_in * 0.9999f);
-    }
-    return any;
-}
-
 // MODE 5 tiles its spheres by position: a square grid of G x G cells over x in [g0, g3], z in [g1, g4] (cell size
 // 1 / g2), and every sphere that lives in a cell has its centre in that cell, radius <= g7 and its whole extent within
 // y in [g5, g6] (rt_api.hip).  Which cells can hold a sphere the ray o + t d, t > 0, hits?  The hit point lies on the
@@ -399,9 +365,16 @@ __device__ __forceinline__ bool ray_may_reach_boxes(D3 o, D3 d, const float (&bo
 // [g0 - g7, g3 + g7] x [g5, g6] x [g1 - g7, g4 + g7], take the xz bounding rectangle of the clipped piece, grow it by
 // g7 and return the cells it overlaps: columns ix0 .. ix0 + nx - 1, rows iz0 .. iz0 + nz - 1; the return value is
 // nx * nz, 0 when the ray misses the box, -1 when the question cannot be answered (the wave then scans every tile).
-// f32 arithmetic, biased to include: the margins of ray_may_reach_boxes (e on every face of the box, the 0.9999 on the
-// interval); the two end points carry the slab parameters' error (<= 3e-7 relative, on a length <= |o| + the scene's
-// size) and their own rounding: 3 e more; the cell coordinates are rounded by 1e-3 cells outwards.
+// f32 arithmetic, biased to include:
+//   * o and d are rounded to f32 (6e-8 relative each): the line they define stays within 6e-8 (|o| + L) of the true
+//     one at distance L, and a sphere can only matter for L <= |o| + the scene's size (`scale`: the sum over the axes
+//     of the largest |coordinate| the grid's box reaches), so the box is grown by e = 1e-6 (|o|_1 + scale) on every side;
+//   * v_rcp_f32 and the products put <= 3e-7 relative error on each slab parameter: the interval test calls the
+//     clipped piece empty only if the exit parameter lies below 0.9999 of the entry parameter; the two end points
+//     carry that error on a length <= |o| + scale, and their own rounding: the rectangle is grown by g7 + 4 e;
+//   * the cell coordinates are rounded 1e-3 cells outwards;
+//   * a direction component of magnitude < 1e-30, |o| or |d| beyond 1e15, an end point beyond 1e30 or a NaN: "cannot
+//     tell" (-1).
 __device__ __forceinline__ int grid_cells(D3 o, D3 d, const float (&g)[8], int G, float scale, int &ix0, int &nx, int &iz0, int &nz)
 {
     const float of[3] = {(float)o.x, (float)o.y, (float)o.z};

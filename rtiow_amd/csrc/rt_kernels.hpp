@@ -69,12 +69,7 @@ struct KParams {
 #endif
     const uint4 *btube;        // [tiles/2 + 1][64] MODE 5 B operands: 32 spheres x 16 K-slots, each column scaled by 2 / its bound (rt_device.hpp)
     float tube_rho;            // MODE 5 radius floor
-    // MODE 5: up to kMaxBoxes axis-aligned boxes (rounded outwards) that together hold every sphere of the filter
-    // tables (the always-exact ones excluded): one per sphere that is much larger than the rest, one around the rest.
-    // A NEW CAMERA RAY that can reach none of them has nothing to scan (rt_device.hpp, ray_may_reach_boxes).
-    float boxes[4][6];         // [k] = lo x, y, z, hi x, y, z
-    float box_scale;           // sum over axes of the largest |coordinate| of any box
-    int32_t n_boxes;
+    float scene_scale;         // MODE 5: sum over axes of the largest |coordinate| a scanned sphere reaches (error margins of grid_cells)
     // MODE 5: the table's columns are ordered by position (rt_api.hip): tiles [0, n_global) hold the spheres every
     // ray scans, tile n_global + iz * grid_dim + ix those whose centre lies in cell (ix, iz) of a square xz grid.
     const double *geo_slot;    // [columns][4] exact (cx, cy, cz, r*r) in column order
@@ -654,14 +649,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             if constexpr (TUBE) {
                 if (alive)
                     for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e]); }
-                // Camera rays into the sky: in the image rows above the scene every lane of a wave starts a new
-                // camera ray in every pass, and none of them can reach a sphere.  When ALL rays of a pass are new
-                // camera rays (one ballot; practically never true elsewhere) they are tested against the scene's
-                // bounding boxes, and a wave in which no ray reaches one skips operands, tile loop and pool (16-ray
-                // groups without such a ray skip their MFMAs).  Conservative like the filter: never changes a result.
-                bool scan = alive;
-                if (__ballot(alive && !fresh) == 0ull)      // (wave-uniform) every ray of this pass is a new camera ray
-                    scan = alive && (P.n_boxes < 0 || ray_may_reach_boxes(o, d, P.boxes, P.n_boxes, P.box_scale));
+                const bool scan = alive;
                 const unsigned long long scan_mask = __ballot(scan);
                 if (scan_mask != 0ull) {
                 const TubeRay T = scan ? make_tube(o, d, P.tube_rho) : no_tube_ray();
@@ -751,7 +739,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 if (P.grid_dim > 0) {
                     int ix0 = 0, nx = 0, iz0 = 0, nz = 0, cnt = 0;
                     RT_STAMP(5);
-                    if (scan && T.sane) cnt = grid_cells(o, d, P.grid, P.grid_dim, P.box_scale, ix0, nx, iz0, nz);
+                    if (scan && T.sane) cnt = grid_cells(o, d, P.grid, P.grid_dim, P.scene_scale, ix0, nx, iz0, nz);
                     RT_STAMP(7);
                     const int gcells = P.grid_dim * P.grid_dim;
                     if (P.n_global + gcells <= 64) {

@@ -6,13 +6,15 @@ import torch  # noqa
 from rtiow_amd import _ffi
 _ffi.LIB_PATH = os.environ.get("RTIOW_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib_stamps.so")   # tools/build_diag_libs.sh
 import rtiow_amd as rt
-names = ["(a) fetch item", "(b) camera ray", "(d) exact tests (list)", "-", "(e) shade+accumulate", "(d) operands + always-exact", "(d) matrix tile loop", "(d) bitmap -> list"]
+names = ["(a) take / start samples", "-", "(d) exact tests (pool)", "(d) tile list", "(e) shade+accumulate", "(d) operands + always-exact", "(d) matrix tile loop", "(d) footprints"]
 for mode in [int(x) for x in os.environ.get("MODES", "4").split(",")]:
     os.environ["RTIOW_SCAN_MODE"] = str(mode)
     r = rt.Renderer(0)
-    r.upload_scene(rt.random_scene(1).flatten())
+    big = os.environ.get("SCENE") == "cfg4"                      # the 10k-sphere scene instead of the book scene
+    r.upload_scene(rt.random_scene(1, grid=(-50, 49) if big else (-11, 11)).flatten())
+    w, h, spp = (1920, 1080, 32) if big else (1200, 675, 100)
     for _ in range(2):
-        sm, fix, st = r.render(rt.book1_camera(1200, 675), rt.make_params(1200, 675, 100), want_fix=False)
+        sm, fix, st = r.render(rt.book1_camera(w, h), rt.make_params(w, h, spp), want_fix=False)
     out = (C.c_ulonglong * 8)()
     r._lib.rt_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     r._lib.rt_debug_phase_cycles(r._h, out)
