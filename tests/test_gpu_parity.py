@@ -344,17 +344,17 @@ def test_position_tiled_scan_bit_exact_on_awkward_layouts(renderer, oracle_mod, 
     assert np.array_equal(fix, fix2)
 
 
-@pytest.mark.parametrize("scale,cam_far,t_min", [(1e11, 2e4, 1e-4), (1e-13, 1.0, 1e-17)])
-def test_rays_and_scenes_outside_the_filters_analysed_range(renderer, oracle_mod, scale, cam_far, t_min):
+@pytest.mark.parametrize("scale,cam_far,t_min,n", [(1e11, 2e4, 1e-4, 150), (1e11, 2e4, 1e-4, 3000), (1e-13, 1.0, 1e-17, 150)])
+def test_rays_and_scenes_outside_the_filters_analysed_range(renderer, oracle_mod, scale, cam_far, t_min, n):
     """A camera 2.7e16 away from a scene of size 1e12 (|o| >= 1e15: the f32 filter and the grid footprint both answer
     "cannot tell" for the camera rays, which then test every sphere exactly while their wave scans every tile; the
     bounce rays are back inside the range), and a scene of size 1e-12 (radii squared below 1e-30, directions squared
     below 1e-20): the same bits as the oracle."""
     rng = np.random.default_rng(5)
-    n = 150
+    half = 8.0 if n < 1000 else 40.0                    # (3000 spheres: a grid of more than 64 cells)
     flat = np.zeros(n + 1, dtype=rt.SPHERE_DTYPE)
     flat["center"][0], flat["radius"][0] = (0.0, -1000.0 * scale, 0.0), 1000.0 * scale
-    flat["center"][1:] = rng.uniform(-8, 8, (n, 3)) * (1, 0.0, 1) * scale + (0, 0.3 * scale, 0)
+    flat["center"][1:] = rng.uniform(-half, half, (n, 3)) * (1, 0.0, 1) * scale + (0, 0.3 * scale, 0)
     flat["radius"][1:] = rng.uniform(0.1, 0.3, n) * scale
     flat["kind"] = rng.integers(0, 3, n + 1)
     flat["kind"][0] = 0
