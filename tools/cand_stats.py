@@ -1,4 +1,5 @@
-import sys; sys.path.insert(0,'/root/repo')
+"""Diagnostic: candidates and exact roots per ray on the book scene (RT_FLAG_DIAG_STATS)."""
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rtiow_amd as rt
 r = rt.Renderer(0)
 r.upload_scene(rt.random_scene(1).flatten())

@@ -1,4 +1,5 @@
-"""Diagnostic: kernel time of configs[1] and configs[3] for several RTIOW_GRID_FILL values (spheres per grid cell aimed at)."""
+"""Diagnostic: kernel time of configs[1] and configs[3] (at 64 spp) for several grid resolutions (RTIOW_GRID_DIM = cells
+per side of the tile grid, 0 = the library's own choice).  usage: python tools/grid_dim_sweep.py 0 4 5 18 19 20"""
 import os, sys, subprocess, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
@@ -16,6 +17,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps(out))
 else:
     for f in sys.argv[1:]:
-        env = dict(os.environ, RTIOW_GRID_FILL=f)
+        env = dict(os.environ, RTIOW_GRID_DIM=f)
         p = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
-        print("fill", f, p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-300:], flush=True)
+        print("grid_dim", f, p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-300:], flush=True)

@@ -1,3 +1,5 @@
+"""Diagnostic: how many workgroups the launch gets (rt_stats.grid_blocks; 1024 = four per CU) and cfg2's kernel time
+for a given build of the library.  usage: python tools/occ_check.py path/to/lib.so"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["RTIOW_HIP_LIB"] = sys.argv[1]
