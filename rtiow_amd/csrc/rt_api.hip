@@ -351,10 +351,11 @@ TileLayout tile_layout(const rt_sphere *spheres, int n, const char *never)
     TileLayout L;
     // ---- which column of the table holds which sphere --------------------------------------------------
     // Spheres are put into tiles of 32 columns by WHERE they are, so that a wave only scans the tiles its rays
-    // can reach (rt_device.hpp, mark_grid_cells): a square grid over the xz extent of the small spheres, one tile
-    // per cell (about 20 spheres per cell on average; what does not fit a cell's 32 columns overflows), preceded
-    // by "global" tiles that every ray scans: spheres too large for a cell and the overflow.  The order of the
-    // columns decides nothing: ties are resolved on the spheres' positions in the caller's list (slot_orig).
+    // can reach (rt_device.hpp, grid_cells): a square grid over the xz extent of the small spheres, one tile
+    // per cell (what does not fit a cell's 32 columns overflows), preceded by "global" tiles that every ray scans:
+    // spheres too large for a cell and the overflow.  The order of the columns decides nothing: ties are resolved
+    // on the spheres' positions in the caller's list (slot_orig).  Diagnostic knobs, read at upload:
+    // RTIOW_NO_GRID=1 (columns in list order, every tile scanned), RTIOW_GRID_DIM=G (cells per side).
     std::vector<int> filtered;
     for (int i = 0; i < n; ++i) if (!never[i]) filtered.push_back(i);
     std::vector<int> &slot_of = L.slot_of;
