@@ -671,17 +671,15 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 };
                 const int col32 = lane & 31, hh = lane >> 5;
                 const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                // which 16-ray groups hold at least one ray to scan (wave-uniform)
-                const unsigned groups = ((scan_mask & 0xFFFFull) ? 1u : 0u) | ((scan_mask & 0xFFFF0000ull) ? 2u : 0u) |
-                                        ((scan_mask & 0xFFFF00000000ull) ? 4u : 0u) | ((scan_mask >> 48) ? 8u : 0u);
                 // results of one MFMA: acc[8bb + j] / acc[8bb + 4 + j] are H_1 / H_2 of ray 16G + 8bb + 4hh + j against
                 // sphere 32 t + col32, in units of half the sphere's bound (the host scales every column): the pair is
                 // kept iff |H_1| < 2 and |H_2| < 2, i.e. iff bit 30 of BOTH f32 patterns is clear (biased exponent
-                // < 128; infinities and NaNs have it set).  So the look is bit logic: X = AND over the lane's 8 rays of
-                // (H_1 | H_2) -- one v_or_b32 and seven v_bitop3_b32 (a & (b | c)) -- has bit 30 clear iff some ray
-                // keeps this sphere, and ONE compare |X| < 2.0 reads that bit.  9 vector instructions of 2.7-4.9 SIMD
-                // cycles where max/min-trees took 14 of 4.3-5.4 (tools/valu_cost_table.hip: v_max/v_min* cost 4.3-5.4
-                // cycles at four waves per SIMD, v_or/v_bitop3 2.7-3.1): 58 instead of 81 cycles per MFMA + look.
+                // < 128; infinities and NaNs have it set).  So the look is bit logic: X_bb = AND over the lane's four rays
+                // 8 bb + j of (H_1 | H_2) -- one v_or_b32 and three v_bitop3_b32 (a & (b | c)) per half -- has bit 30
+                // clear iff one of them keeps this sphere, and ONE compare |X_0 & X_1| < 2.0 reads that bit for the
+                // wave-level branch; behind it the two halves are tested as they are.  10 vector instructions of
+                // 2.7-4.9 SIMD cycles where max/min-trees took 14 of 4.3-5.4 (tools/valu_cost_table.hip: v_max/v_min*
+                // cost 4.3-5.4 cycles at four waves per SIMD, v_or/v_bitop3 2.7-3.1).
                 auto keeps = [](uint32_t x) -> bool { return __builtin_fabsf(__uint_as_float(x)) < kTubeKeepBelow; };
                 auto look_tube = [&](int G, const f32x16 &acc, int wrel) {
                     // X_bb: the AND over the four rays 8 bb + j of this lane; the wave-level branch tests X_0 & X_1
@@ -828,8 +826,10 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                         look_tube(2, acc0, w);
                         look_tube(3, acc1, w);
                     };
-                    if (__builtin_expect(groups == 0xFu, 1)) {
-                        // B operands ping-pong between two register sets, each fetched a tile ahead
+                    {
+                        // B operands ping-pong between two register sets, each fetched a tile ahead.  (All four 16-ray
+                        // groups go through the matrix pipe even when some hold no ray -- their rows keep nothing: a
+                        // second loop for the launch's last waves cost more in code than it saved, 1.8 % of the frame.)
                         bf16x8 bp = load_b(tile_at(0)), bq;
                         int w = 0;
                         for (; w + 1 < nwords; w += 2) {
@@ -839,19 +839,6 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                             do_tile(w + 1, bq);
                         }
                         if (w < nwords) do_tile(w, bp);
-                    } else {
-                        // end of the launch / sky rows: some 16-ray groups of this wave have no ray to scan;
-                        // only the groups with one go through the matrix pipe and the look
-                        for (int w = 0; w < nwords; ++w) {
-                            RT_COUNT(7);
-                            const bf16x8 b = load_b(tile_at(w));
-#pragma unroll
-                            for (int G = 0; G < 4; ++G)
-                                if (groups & (1u << G)) {
-                                    const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[G], b, zero16, 0, 0, 0);
-                                    look_tube(G, acc, w);
-                                }
-                        }
                     }
                     __builtin_amdgcn_wave_barrier();
                     RT_STAMP(6);
