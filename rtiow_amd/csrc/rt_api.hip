@@ -298,13 +298,13 @@ int upload_table(T **dst, const T *src, size_t count)
     return RT_OK;
 }
 
-template <int MODE, bool DIAG>
+template <int MODE, bool DIAG, bool SMALLGRID = false>
 int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, int *grid_out)
 {
     int per_cu = ctx->blocks_per_cu;
     if (per_cu <= 0) {
         int occ = 0;
-        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rt::render_kernel<MODE, DIAG>, rt::kBlock, 0));
+        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rt::render_kernel<MODE, DIAG, SMALLGRID>, rt::kBlock, 0));
         per_cu = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
     }
     // persistent grid, but never more lanes than there are work items
@@ -314,7 +314,7 @@ int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, in
     if (grid < 1) grid = 1;
     *grid_out = (int)grid;
     RT_HIP(hipEventRecord(ctx->ev0, stream));
-    hipLaunchKernelGGL((rt::render_kernel<MODE, DIAG>), dim3((unsigned)grid), dim3(rt::kBlock), 0, stream, kp);
+    hipLaunchKernelGGL((rt::render_kernel<MODE, DIAG, SMALLGRID>), dim3((unsigned)grid), dim3(rt::kBlock), 0, stream, kp);
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(ctx->ev1, stream));
     return RT_OK;
@@ -786,7 +786,10 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     case 8: rc = launch_render<4, false>(ctx, kp, stream, &grid); break;
     case 9: rc = launch_render<4, true>(ctx, kp, stream, &grid); break;
 #endif
-    case 10: rc = launch_render<5, false>(ctx, kp, stream, &grid); break;
+    case 10:        // (the shipped kernel has a leaner instantiation for scenes whose tile grid has <= 64 cells)
+        if (ctx->grid_dim > 0 && ctx->n_global + ctx->grid_dim * ctx->grid_dim <= 64) rc = launch_render<5, false, true>(ctx, kp, stream, &grid);
+        else rc = launch_render<5, false>(ctx, kp, stream, &grid);
+        break;
     default: rc = launch_render<5, true>(ctx, kp, stream, &grid); break;
     }
     if (rc) return rc;

@@ -140,7 +140,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // DIAG: also count filter candidates, exact roots and rays per bounce index (rt_stats.candidates /
 // exact_roots / live_per_bounce).  Off in the shipped path: the counters cost spilled registers and
 // ~15 % of the frame time.
-template <int MODE, bool DIAG>
+// SMALLGRID (MODE 5 only): the scene's tile grid has at most 64 cells (with the global tiles: a list of <= 64 tiles) --
+// the host picks this instantiation then; it carries neither the large-grid list code nor the scan-every-tile fallback.
+template <int MODE, bool DIAG, bool SMALLGRID = false>
 // second launch bound = waves per SIMD the register allocator must leave room for: the bounce loop
 // is latency-bound, and the 4th wave is worth more than the few cold values it spills.  Only the shipped kernel
 // (MODE 5 without the diagnostic counters) fits four workgroups' LDS on a CU (40 000 of 40 960 bytes each); the
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                             summary &= summary - 1u;
                             word = bits_w[w * 64 + lane];
                             if constexpr (TUBE)         // seg0: position in the tile list of the segment's first tile
-                                wbase = 32 * (list_all ? seg0 + w : (int)bits_w[(kSeg / 2) * 64 + seg0 + w]);
+                                wbase = 32 * (!SMALLGRID && list_all ? seg0 + w : (int)bits_w[(kSeg / 2) * 64 + seg0 + w]);
                             else
                                 wbase = 16 * seg0 + 32 * w;
                         }
@@ -734,13 +736,13 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
                     return v;
                 };
-                if (P.grid_dim > 0) {
+                if (SMALLGRID || P.grid_dim > 0) {
                     int ix0 = 0, nx = 0, iz0 = 0, nz = 0, cnt = 0;
                     RT_STAMP(5);
                     if (scan && T.sane) cnt = grid_cells(o, d, P.grid, P.grid_dim, P.scene_scale, ix0, nx, iz0, nz);
                     RT_STAMP(7);
                     const int gcells = P.grid_dim * P.grid_dim;
-                    if (P.n_global + gcells <= 64) {
+                    if (SMALLGRID || P.n_global + gcells <= 64) {
                         // a small grid: the cells fit ONE 64-bit mask per ray (bit iz * grid_dim + ix); the wave's set
                         // of cells is the OR over its lanes, taken in registers, and lane c finds the place of cell c's
                         // tile in the list by counting the set cells below it
@@ -762,7 +764,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                         __builtin_amdgcn_wave_barrier();
                         list_all = false;
                         n_list = P.n_global + __builtin_popcountll(cells);
-                    } else if (__ballot(cnt < 0) == 0ull) {
+                    } else if (!SMALLGRID && __ballot(cnt < 0) == 0ull) {
                         // a large grid: one 64-bit word per grid ROW in LDS, ORed by the rays; lane l then owns row l,
                         // a prefix sum over the rows' cell counts gives each row its place in the list
                         unsigned long long *tm = reinterpret_cast<unsigned long long *>(bits_w);   // (512 B of the bitmap area, free until the tile loop)
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     const int nwords = min(kSeg / 2, n_list - t0);          // one bitmap word per 32-sphere tile
                     for (int w = 0; w < nwords; ++w) bits_w[w * 64 + lane] = 0u;
                     // the segment's tiles (and two more for the look-ahead), one per lane
-                    const int listv = list_all ? min(t0 + lane, ntt) : (int)tl[min(t0 + lane, kListCap + 1)];
+                    const int listv = !SMALLGRID && list_all ? min(t0 + lane, ntt) : (int)tl[min(t0 + lane, kListCap + 1)];
                     auto tile_at = [&](int j) -> int { return __builtin_amdgcn_readlane(listv, j); };      // j < 20, wave-uniform
                     __builtin_amdgcn_wave_barrier();
                     // one 32-sphere tile: four independent MFMAs (one per 16-ray group); two results in
