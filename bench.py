@@ -219,6 +219,7 @@ def main():
             kernel_ms.append(st["kernel_ms"])
             rays, samples = st["rays_traced"], st["samples"]
             step.scan_mode = st["scan_mode"]
+            step.kernel_variant = st.get("kernel_variant", 0)
 
     def fence():
         torch.cuda.synchronize()
@@ -228,6 +229,7 @@ def main():
 
     step.last_full = None
     step.scan_mode = -1
+    step.kernel_variant = 0
 
     for _ in range(args.warmup):
         step(False)
@@ -277,7 +279,7 @@ def main():
             # a property of kernel + configuration) / this run's kernel time; `frac` = the share of SIMD cycles in which
             # a vector instruction is issuing (SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles), replayed); `peak` =
             # achieved / frac: the rate this instruction mix would issue at with no idle SIMD cycle.
-            "bound": "valu-issue", "kernel": f"rt::render_kernel<{step.scan_mode}, false>",
+            "bound": "valu-issue", "kernel": f"rt::render_kernel<{step.scan_mode}, false, {'true' if step.kernel_variant else 'false'}>",
             "achieved": None, "peak": None, "unit": "G vector wave-instructions/s", "frac": None,
             "kernel_ms": round(k_ms, 3), "kernel_ms_source": "HIP events on the launch stream, this run",
             "launches_timed": len(kernel_ms),

@@ -94,7 +94,7 @@ pub struct rt_stats {
     pub grid_blocks: i32,
     pub block_threads: i32,
     pub scan_mode: i32,
-    pub reserved: i32,
+    pub kernel_variant: i32,
     pub live_per_bounce: [u64; 64],
     pub direct_samples: u64,
 }

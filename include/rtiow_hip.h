@@ -121,7 +121,8 @@ typedef struct {
     int32_t  grid_blocks, block_threads;
     int32_t  scan_mode;          /* sphere-scan filter that ran: 0 none (RT_FLAG_NO_FILTER), 5 tube filter (shipped),
                                     1 VALU cross-check (RTIOW_SCAN_MODE=1); 2-4 only in RTIOW_CROSSCHECK_MODES builds */
-    int32_t  reserved;
+    int32_t  kernel_variant;     /* which instantiation of the scan_mode-5 kernel ran: 1 the one for scenes whose tile
+                                    grid has <= 64 cells, 0 the general one (and every other scan mode) */
     uint64_t live_per_bounce[64]; /* rays traced at bounce index k (0 = camera ray; indices >= 63 share the
                                     last slot); sums to rays_traced (RT_FLAG_DIAG_STATS, else 0) */
     uint64_t direct_samples;     /* samples added to the frame buffer one by one instead of through their block's

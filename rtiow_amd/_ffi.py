@@ -34,7 +34,7 @@ class rt_params(C.Structure):
 class rt_stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays_traced", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("candidates", C.c_uint64), ("exact_roots", C.c_uint64), ("kernel_ms", C.c_float), ("n_spheres", C.c_int32),
-                ("grid_blocks", C.c_int32), ("block_threads", C.c_int32), ("scan_mode", C.c_int32), ("reserved", C.c_int32),
+                ("grid_blocks", C.c_int32), ("block_threads", C.c_int32), ("scan_mode", C.c_int32), ("kernel_variant", C.c_int32),
                 ("live_per_bounce", C.c_uint64 * 64), ("direct_samples", C.c_uint64)]
 
 

@@ -773,6 +773,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     const bool diag = (p->flags & RT_FLAG_DIAG_STATS) != 0;
     const int mode = (p->flags & RT_FLAG_NO_FILTER) ? 0 : ctx->scan_mode;
     ctx->last.scan_mode = mode;
+    ctx->last.kernel_variant = 0;
     switch (mode * 2 + (diag ? 1 : 0)) {
     case 0: rc = launch_render<0, false>(ctx, kp, stream, &grid); break;
     case 1: rc = launch_render<0, true>(ctx, kp, stream, &grid); break;
@@ -787,8 +788,10 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     case 9: rc = launch_render<4, true>(ctx, kp, stream, &grid); break;
 #endif
     case 10:        // (the shipped kernel has a leaner instantiation for scenes whose tile grid has <= 64 cells)
-        if (ctx->grid_dim > 0 && ctx->n_global + ctx->grid_dim * ctx->grid_dim <= 64) rc = launch_render<5, false, true>(ctx, kp, stream, &grid);
-        else rc = launch_render<5, false>(ctx, kp, stream, &grid);
+        if (ctx->grid_dim > 0 && ctx->n_global + ctx->grid_dim * ctx->grid_dim <= 64) {
+            rc = launch_render<5, false, true>(ctx, kp, stream, &grid);
+            ctx->last.kernel_variant = 1;
+        } else rc = launch_render<5, false>(ctx, kp, stream, &grid);
         break;
     default: rc = launch_render<5, true>(ctx, kp, stream, &grid); break;
     }
