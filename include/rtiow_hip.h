@@ -187,6 +187,9 @@ int32_t rt_abi_version(void);
  * two operations whose correct rounding the bit-exact contract leans on). */
 int rt_f64_div_sqrt_device(rt_context *ctx, const double *a, const double *b, int32_t n,
                            double *out_div, double *out_sqrt);
+/* ... and the kernel's quantisation of one radiance channel to the exact 2^-32 grid (contract C5, DESIGN.md
+ * section 4): out[i] = floor(min(x[i], 2^30) * 2^32) for x[i] >= 0, and 0 for negatives and NaN. */
+int rt_quantize_device(rt_context *ctx, const double *x, int32_t n, uint64_t *out);
 /* Known-answer hooks of the EARLIER matrix-pipe forms of the filter (scan modes 2-4).
  * They exist only in a library built with -DRTIOW_CROSSCHECK_MODES (tools/librtiow_hip_xcheck.so, a test
  * artefact); the product library carries scan modes 0, 1 and 5 and does not export them. */

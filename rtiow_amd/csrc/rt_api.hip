@@ -937,6 +937,24 @@ int rt_f64_div_sqrt_device(rt_context *ctx, const double *a, const double *b, in
     return RT_OK;
 }
 
+int rt_quantize_device(rt_context *ctx, const double *x, int32_t n, uint64_t *out)
+{
+    if (!ctx || !x || !out || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)n * sizeof(double);
+    int rc = ensure(&ctx->d_stage_fix, &ctx->stage_fix_bytes, 2 * bytes);
+    if (rc) return rc;
+    double *dx = (double *)ctx->d_stage_fix;
+    unsigned long long *dq = (unsigned long long *)(dx + n);
+    RT_HIP(hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, ctx->own_stream));
+    hipLaunchKernelGGL(rt::quantize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->own_stream, (const double *)dx, (int)n, dq);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemcpyAsync(out, dq, bytes, hipMemcpyDeviceToHost, ctx->own_stream));
+    RT_HIP(hipStreamSynchronize(ctx->own_stream));
+    return RT_OK;
+}
+
 #ifdef RTIOW_CROSSCHECK_MODES
 int rt_filter_products_device(rt_context *ctx, const float *r1, const float *r2, const float *s,
                                int32_t bf16x3, float *out_hb, float *out_q)

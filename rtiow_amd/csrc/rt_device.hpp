@@ -105,11 +105,15 @@ __device__ __forceinline__ bool unit_sphere_accepts(uint32_t wx, uint32_t wy, ui
 }
 
 // Contract C5: truncate one radiance channel to the 2^-32 grid.
+// (= (unsigned long long)(x * 2^32) for 0 <= x <= 2^30, 0 for NaN and negatives, 2^62 above -- written so that it
+//  compiles to 7 instructions instead of the 13 of a generic f64 -> u64 conversion: the integer part converts
+//  exactly (v_cvt_u32_f64 truncates), the rest x - hi is exact, and so is its product with 2^32)
 __device__ __forceinline__ unsigned long long quantize(double x)
 {
-    if (!(x >= 0.0)) return 0ull;               // NaN and negatives
-    if (x > 1073741824.0) x = 1073741824.0;     // 2^30
-    return (unsigned long long)(x * 4294967296.0);
+    x = __builtin_fmin(__builtin_fmax(x, 0.0), 1073741824.0);       // NaN -> 0: maxNum(NaN, 0) is 0 (the max FIRST)
+    const uint32_t hi = (uint32_t)x;
+    const uint32_t lo = (uint32_t)((x - (double)hi) * 4294967296.0);
+    return ((unsigned long long)hi << 32) | (unsigned long long)lo;
 }
 
 // ---- the f32 filter of the sphere scan ----------------
@@ -456,23 +460,35 @@ __device__ __forceinline__ TubeRay no_tube_ray()
     return T;
 }
 
-// the two rows of a ray as 2 x 8 dwords (two bf16 each, low half = even K-slot)
+// the two rows of a ray as 2 x 8 dwords (two bf16 each, low half = even K-slot).  The pieces are the hardware's
+// round-to-nearest-even conversions, two per instruction (v_cvt_pk_bf16_f32): converting (x, x) gives the dword
+// p1 | p1 << 16 at once, and its high half IS the f32 value of the piece.
 __device__ __forceinline__ void tube_a_words(const TubeRay &T, uint32_t (&w)[2][8])
 {
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    auto pk = [](float lo, float hi) -> uint32_t {
+        const f32x2v v = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
+    };
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const float x = T.u[k][i];
-            const uint32_t p1 = (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)x);
-            const float r1 = x - __uint_as_float(p1 << 16);
-            const uint32_t p2 = (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)r1);
-            w[k][2 * i + 0] = p1 | (p1 << 16);
-            w[k][2 * i + 1] = p2 | (p2 << 16);
+            const uint32_t d1 = pk(x, x);                                       // p1 | p1 << 16
+            const float r1 = x - __uint_as_float(d1 & 0xFFFF0000u);
+            w[k][2 * i + 0] = d1;
+            w[k][2 * i + 1] = pk(r1, r1);                                       // p2 | p2 << 16
         }
-        const Bf3 t = split_bf16x3_hw(T.t[k]);
-        w[k][6] = t.p1 | (t.p2 << 16);
-        w[k][7] = t.p3 | (kBf16One << 16);          // slot 15: 1 (against 0, or 4 in a never-kept column)
+        // t in three pieces (the third is exact: at most 8 significant bits are left), then the 1 of K-slot 15
+        const float t = T.t[k];
+        const uint32_t c1 = pk(t, t);
+        const float r1 = t - __uint_as_float(c1 & 0xFFFF0000u);
+        const uint32_t c2 = pk(r1, r1);
+        const float r2 = r1 - __uint_as_float(c2 & 0xFFFF0000u);
+        w[k][6] = (c1 & 0xFFFFu) | (c2 & 0xFFFF0000u);                          // p1 | p2 << 16
+        w[k][7] = pk(r2, 1.0f);                     // p3 | 1 << 16; slot 15: 1 (against 0, or 4 in a never-kept column)
     }
 }
 

@@ -1408,4 +1408,11 @@ __global__ void f64_div_sqrt_kernel(const double *a, const double *b, int n, dou
     if (k < n) { q[k] = a[k] / b[k]; r[k] = __builtin_sqrt(a[k]); }
 }
 
+// known-answer hook: the kernel's own quantize() (contract C5) on n radiance values
+__global__ void quantize_kernel(const double *x, int n, unsigned long long *q)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) q[k] = quantize(x[k]);
+}
+
 } // namespace rt

@@ -151,6 +151,14 @@ class Renderer:
                                                     r.ctypes.data_as(C.c_void_p)), "rt_f64_div_sqrt_device")
         return q, r
 
+    def quantize(self, x):
+        """The kernel's own quantisation of radiance values to the 2^-32 grid (known-answer test hook)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        q = np.zeros(x.shape, dtype=np.uint64)
+        _ffi.check(self._lib.rt_quantize_device(self._h, x.ctypes.data_as(C.c_void_p), int(x.size), q.ctypes.data_as(C.c_void_p)),
+                   "rt_quantize_device")
+        return q
+
     def filter_products(self, r1, r2, s, bf16x3=True):
         """Matrix-pipe filter products HB = R1 x S^T, Q = R2 x S^T of scan modes 2/3 (known-answer test
         hook; cross-check build only)."""

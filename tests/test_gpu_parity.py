@@ -147,6 +147,26 @@ def test_f64_divide_and_sqrt_are_correctly_rounded_on_device(renderer):
     assert np.array_equal(q, a / b) and np.array_equal(s, np.sqrt(a))
 
 
+def test_quantize_on_device_is_the_oracles(renderer, oracle_mod):
+    """Contract C5 on the device (rt_quantize_device runs the kernel's own quantize()): floor(min(x, 2^30) 2^32) for
+    x >= 0, 0 for negatives and NaN -- on the edge values and on 2^18 random radiances of every magnitude."""
+    lib = oracle_mod.load()
+    rng = np.random.default_rng(9)
+    x = np.abs(rng.standard_normal(1 << 18)) * 10.0 ** rng.integers(-40, 12, 1 << 18)
+    x[1::7] *= -1.0
+    edge = [0.0, -0.0, 1.0, 0.5, 2.0 ** -33, 2.0 ** -32, np.nextafter(2.0 ** -32, 0.0), 1.0 - 2.0 ** -53, 1e30, 2.0 ** 30,
+            np.nextafter(2.0 ** 30, 0.0), np.nextafter(2.0 ** 30, np.inf), np.inf, -np.inf, np.nan, -1.0, 5e-324, 4294967295.75,
+            123456.789, 2.0 ** 29 + 2.0 ** -23]
+    x[:len(edge)] = edge
+    q = renderer.quantize(x)
+    want = np.array([lib.oracle_b_quantize(float(v)) for v in x[:4096]], dtype=np.uint64)
+    assert np.array_equal(q[:4096], want)
+    # the rest against the definition in numpy (exact: scaling by 2^32, truncation)
+    xs = np.where(np.isnan(x) | (x < 0), 0.0, np.minimum(x, 2.0 ** 30))
+    ref = np.floor(xs).astype(np.uint64) * np.uint64(1 << 32) + np.floor((xs - np.floor(xs)) * 2.0 ** 32).astype(np.uint64)
+    assert np.array_equal(q, ref)
+
+
 def test_errors(renderer, book1_flat):
     fresh = rt.Renderer(0)
     try:
