@@ -50,6 +50,11 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md, dense bf16 matrix 
 FLOP_PER_TEST = 17                     # per ray-sphere test
 FLOP_PER_RAY_FIXED = 65                # hit finalisation + shading per ray
 N_SIMD = 1024                          # 256 CUs x 4 SIMDs
+SPEC_CLOCK_GHZ = 2.4                   # MI355X_MICROARCH.md: peak engine clock
+# hardware issue cost of one wave64 vector instruction on a SIMD-32 (MI355X_MICROARCH.md, "Per-instruction cycle
+# constants"): 2 cycles for f32/int/bit ops, 4 for f64 add/mul/fma (78.6 TFLOP/s f64 vector peak = 16 lanes/clk/SIMD),
+# 8 for the transcendental unit (v_rcp/v_rsq/v_sqrt_f32)
+ISSUE_CYCLES = {"plain": 2.0, "f64": 4.0, "trans": 8.0}
 
 KERNEL_SOURCES = ("rtiow_amd/csrc/rt_kernels.hpp", "rtiow_amd/csrc/rt_device.hpp", "rtiow_amd/csrc/rt_api.hip")
 
@@ -75,8 +80,17 @@ def host_cpu_share():
     return n
 
 
-def cpu_baseline(flat, width, height, spp, target_seconds=12.0):
-    """Oracle A on a bounded, evenly strided row subset of the same frame."""
+def baseline_metric():
+    """BASELINE.json's metric string (the bench measures THAT metric); the literal is the fallback on a box without the file."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "Msamples/sec (pixels\u00d7spp) on book-1 final scene; per-pixel RMSE vs CPU"
+
+
+def cpu_baseline(flat, width, height, spp, target_seconds=12.0, min_rows=100):
+    """Oracle A on a bounded, evenly strided row subset of the same frame (at least `min_rows` rows of it: the
+    subset also carries the RMSE-vs-CPU half of the metric).  Returns (json object, rows j, f64 sums [rows, W, 3])."""
     import oracle
     cam = oracle.book1_camera(width, height)
     threads = host_cpu_share()
@@ -84,17 +98,35 @@ def cpu_baseline(flat, width, height, spp, target_seconds=12.0):
     p = oracle.make_params(width, height, max(1, spp // 10), rows=(0, height, probe_step), nthreads=threads)
     _, st = oracle.render_a(cam, flat, p)
     rate = st["samples"] / st["seconds"]
-    rows_wanted = max(1.0, target_seconds * rate / (width * spp))
-    step = int(min(height, max(1, round(height / rows_wanted))))
+    rows_wanted = max(float(min(min_rows, height)), target_seconds * rate / (width * spp))
+    step = int(min(height, max(1, height // int(min(height, round(rows_wanted))))))
     p = oracle.make_params(width, height, spp, rows=(0, height, step), nthreads=threads)
-    _, st = oracle.render_a(cam, flat, p)
+    sums, st = oracle.render_a(cam, flat, p)
     nrows = oracle.n_rows(p)
-    return {
+    obj = {
         "value": round(st["samples"] / st["seconds"] / 1e6, 4), "unit": "Msamples/s",
         "cores": int(st["threads_used"]), "kind": "port",
         "sample": f"Oracle A (literal f64 restatement, oracle/oracle_f64.c), rows j=0,{step},2*{step},... "
                   f"({nrows} of {height} rows) of the {width}x{height}x{spp}spp frame, {st['samples']} samples in "
                   f"{st['seconds']:.2f} s on {st['threads_used']} host threads",
+    }
+    return obj, np.arange(0, height, step, dtype=np.int64)[:nrows], sums
+
+
+def rmse_vs_cpu(gpu_fix_rows, gpu_rgba_rows_bottom_up, cpu_sums, spp):
+    """The second half of BASELINE.json's metric: per-pixel RMSE of the GPU frame against the CPU render of the same
+    rows at matched seeds, on LINEAR radiance means (sqrt(mean over pixels and channels of
+    (GPU_mean - CPU_mean)^2), before gamma) -- main.rs:135-137's pixel_color / spp on both sides -- and whether
+    Color::to_rgba gives the same bytes.  gpu_fix_rows: u64 exact sums [rows, W, 3] (quantum 2^-32)."""
+    import oracle
+    gpu_mean = gpu_fix_rows.astype(np.float64) * (1.0 / 4294967296.0) / spp
+    cpu_mean = cpu_sums / spp
+    diff = gpu_mean - cpu_mean
+    cpu_rgba = oracle.resolve_a(cpu_sums, spp, flip=False)
+    return {
+        "rmse": float(np.sqrt(np.mean(diff * diff))), "max_abs_diff": float(np.abs(diff).max()),
+        "rgba8_rows_identical": bool(np.array_equal(cpu_rgba, gpu_rgba_rows_bottom_up)),
+        "rgba8_bytes_differing": int((cpu_rgba != gpu_rgba_rows_bottom_up).sum()),
     }
 
 
@@ -152,6 +184,10 @@ def main():
                     help="rows per shard tile; 1 balances the ranks to within one row of each other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--weak-baseline", action="store_true",
+                    help="N=1 only: the single-GPU half of SURVEY.md 8(e)'s weak-scaling pair -- BASELINE configs[2], "
+                         "3840x2160x500 = 4.147 G samples, the per-GPU share of the N>1 runs -- as a whole step "
+                         "(render + gather + resolve), so that T(configs[2]) / T(N>1) can be formed from two `value`s")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 logic check on a 1-GPU box: every rank renders on cuda:0 and the gather runs "
                          "over gloo on CPU tensors (RCCL refuses two ranks on one device); not a measurement")
@@ -181,6 +217,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     default_whs = (1200, 675, 500) if world == 1 else (7680, 4320, 125)
+    if args.weak_baseline:
+        if world != 1:
+            sys.exit("--weak-baseline is the N = 1 comparator of the N > 1 runs")
+        default_whs = (3840, 2160, 500)
+        args.no_other_configs = args.no_cpu_baseline = True
     W = args.width or default_whs[0]
     H = args.height or default_whs[1]
     spp_share = args.spp or default_whs[2]
@@ -201,16 +242,26 @@ def main():
     rehearse = args.rehearse_on_one_gpu and world > 1
     gather = FrameGatherer(H, W, args.tile_rows, rank, world, "cpu" if rehearse else dev)
 
-    kernel_ms, rays, samples = [], 0, 0
+    kernel_ms, gather_ms, rays, samples = [], [], 0, 0
+    gather_events = []
 
     def step(record):
         nonlocal rays, samples
         renderer.render_device(cam, params, d_fix.data_ptr(), stream)
         if rehearse:
+            tg = time.perf_counter()
             full = gather(d_fix.cpu())
             full = full.to(dev) if rank == 0 else None
+            if record:
+                gather_ms.append((time.perf_counter() - tg) * 1e3)
         else:
+            # (events on the launch stream: the collective runs on RCCL's stream, which the launch stream waits for)
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
             full = gather(d_fix)
+            eb.record()
+            if record:
+                gather_events.append((ea, eb))
         if rank == 0:
             renderer.resolve_rgba8_device(full.data_ptr(), W, H, spp_frame, 1, d_rgba.data_ptr(), stream)
             step.last_full = full
@@ -239,10 +290,18 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
+    gather_ms += [ea.elapsed_time(eb) for ea, eb in gather_events]
+    per_rank = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # max over ranks of the timed region; every rank's own kernel and gather time (mean per step) for the record
+        t = torch.tensor([elapsed, float(np.mean(kernel_ms)), float(np.mean(gather_ms))], dtype=torch.float64,
+                         device="cpu" if args.rehearse_on_one_gpu else dev)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        elapsed = max(float(q[0].item()) for q in parts)
+        per_rank = {"elapsed_s": [round(float(q[0].item()), 6) for q in parts],
+                    "kernel_ms": [round(float(q[1].item()), 3) for q in parts],
+                    "gather_ms": [round(float(q[2].item()), 3) for q in parts]}
 
     if rank == 0:
         frame_samples = W * H * spp_frame
@@ -274,11 +333,15 @@ def main():
             import zlib
             frame_crc = zlib.crc32(step.last_full.cpu().numpy().tobytes()) & 0xFFFFFFFF
         roof = {
-            # What bounds the kernel is vector-instruction ISSUE: `achieved` = vector (VALU)
-            # wave-instructions issued per second = the instruction count of one launch (SQ_INSTS_VALU, replayed: it is
-            # a property of kernel + configuration) / this run's kernel time; `frac` = the share of SIMD cycles in which
-            # a vector instruction is issuing (SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles), replayed); `peak` =
-            # achieved / frac: the rate this instruction mix would issue at with no idle SIMD cycle.
+            # What bounds the kernel is vector-instruction ISSUE.
+            #   achieved = vector (VALU) wave-instructions issued per second: the instruction count of one launch
+            #              (SQ_INSTS_VALU, replayed: a property of kernel + configuration) / this run's kernel time;
+            #   peak     = what the hardware can issue for THIS instruction mix: 1024 SIMDs x 2.4 GHz / (mean hardware
+            #              issue cycles per instruction: 2 for f32/int/bit, 4 for f64 add/mul/fma, 8 for the
+            #              transcendental unit -- the class counts are replayed PMC counters, the cycles are
+            #              MI355X_MICROARCH.md's constants); `peak_uniform` = 1024 x 2.4 / 2, every instruction at 2 cycles;
+            #   frac     = achieved / peak;  `valu_busy` = the measured share of SIMD cycles in which a vector
+            #              instruction is issuing (SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles)) -- a utilisation, not a roofline.
             "bound": "valu-issue", "kernel": f"rt::render_kernel<{step.scan_mode}, false, {'true' if step.kernel_variant else 'false'}>",
             "achieved": None, "peak": None, "unit": "G vector wave-instructions/s", "frac": None,
             "kernel_ms": round(k_ms, 3), "kernel_ms_source": "HIP events on the launch stream, this run",
@@ -302,26 +365,46 @@ def main():
                 roof["kernel_ms_rocprof_avg"] = pmc["rocprof_avg_kernel_ms"]
             if pmc.get("valu_insts_per_launch") and pmc.get("simd_cycles_per_launch"):
                 wave_bounces = rays / 64.0
-                rate = pmc["valu_insts_per_launch"] / (k_ms * 1e-3) / 1e9
+                n_valu = pmc["valu_insts_per_launch"]
+                rate = n_valu / (k_ms * 1e-3) / 1e9
+                n_f64 = pmc.get("f64_addmulfma_insts_per_launch") or 0.0
+                n_trans = pmc.get("trans_f32_insts_per_launch") or 0.0
+                mean_cycles = ((n_valu - n_f64 - n_trans) * ISSUE_CYCLES["plain"] + n_f64 * ISSUE_CYCLES["f64"]
+                               + n_trans * ISSUE_CYCLES["trans"]) / n_valu
+                peak = N_SIMD * SPEC_CLOCK_GHZ / mean_cycles
                 roof["achieved"] = round(rate, 1)
-                roof["frac"] = pmc.get("valu_busy")
-                roof["peak"] = round(rate / pmc["valu_busy"], 1) if pmc.get("valu_busy") else None
+                roof["peak"] = round(peak, 1)
+                roof["frac"] = round(rate / peak, 4)
+                roof["peak_uniform"] = round(N_SIMD * SPEC_CLOCK_GHZ / ISSUE_CYCLES["plain"], 1)
+                roof["frac_of_peak_uniform"] = round(rate / roof["peak_uniform"], 4)
+                roof["peak_source"] = (f"{N_SIMD} SIMDs x {SPEC_CLOCK_GHZ} GHz / {mean_cycles:.3f} hardware issue cycles per "
+                                       f"instruction of this mix ({n_f64 / n_valu:.3f} f64 add/mul/fma at 4, "
+                                       f"{n_trans / n_valu:.4f} transcendental at 8, the rest at 2)")
+                roof["valu_busy"] = pmc.get("valu_busy")
                 roof["issue"] = {
-                    "valu_insts_per_launch": pmc["valu_insts_per_launch"],
-                    "valu_insts_per_wave_bounce": round(pmc["valu_insts_per_launch"] / wave_bounces, 1),
+                    "valu_insts_per_launch": n_valu,
+                    "valu_insts_per_wave_bounce": round(n_valu / wave_bounces, 1),
+                    # the f64 add/mul/fma the reference's arithmetic REQUIRES (SQ_INSTS_VALU_{ADD,MUL,FMA}_F64): the rest of the
+                    # vector instructions are overhead of this implementation (Philox, the look, lists, conversions, moves)
+                    "required_f64_per_wave_bounce": round(n_f64 / wave_bounces, 1) if n_f64 else None,
+                    "salu_insts_per_wave_bounce": (None if not pmc.get("salu_insts_per_launch") else
+                                                   round(pmc["salu_insts_per_launch"] / wave_bounces, 1)),
+                    "branches_per_wave_bounce": (None if not pmc.get("branch_insts_per_launch") else
+                                                 round(pmc["branch_insts_per_launch"] / wave_bounces, 1)),
                     "mfma_insts_per_wave_bounce": (None if not pmc.get("mfma_insts_per_launch") else
                                                    round(pmc["mfma_insts_per_launch"] / wave_bounces, 1)),
+                    "lds_bank_conflict_share": pmc.get("lds_bank_conflict_share"),
                     # SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (SIMDs x kernel cycles): share of SIMD time in which
                     # a vector instruction is being issued
-                    "frac": pmc.get("valu_busy"),
-                    "cycles_per_valu_inst": round(pmc["simd_cycles_per_launch"] / (pmc["valu_insts_per_launch"] / N_SIMD), 3),
+                    "valu_busy": pmc.get("valu_busy"),
+                    "cycles_per_valu_inst": round(pmc["simd_cycles_per_launch"] / (n_valu / N_SIMD), 3),
                 }
             if pmc.get("mfma_insts_per_launch"):
                 t = pmc["mfma_insts_per_launch"] * 32768 / (k_ms * 1e-3) / 1e12     # v_mfma_f32_32x32x16_bf16 = 32768 flop
                 roof["mfma"] = {"achieved_TFLOPs": round(t, 1), "peak_TFLOPs": PEAK_BF16_MFMA_TFLOPS,
                                 "frac": round(t / PEAK_BF16_MFMA_TFLOPS, 4)}
         out = {
-            "metric": "Msamples/sec (pixels x spp) on book-1 final scene",
+            "metric": baseline_metric(),
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -329,7 +412,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": f"book-1 final scene (random_scene seed 1, {n_sph} spheres), {W}x{H}, {spp_frame} spp, depth 50 "
-                            + (("[the north_star target configuration: BASELINE.json configs[1]'s frame at 500 spp]"
+                            + (("[BASELINE.json configs[2]: the N = 1 half of the weak-scaling pair, 4.147 G samples on one GPU]"
+                                if args.weak_baseline else
+                                "[the north_star target configuration: BASELINE.json configs[1]'s frame at 500 spp]"
                                 if world == 1 else
                                 f"[BASELINE.json configs[4]'s geometry, 125 spp per GPU: {world}/8 of configs[4]; "
                                 f"4.147 G samples per GPU = configs[2] on one GPU]") if is_default else "[custom size]"),
@@ -359,9 +444,29 @@ def main():
                 others.append({"error": str(e)})
             renderer.upload_scene(flat)
             out["other_configs"] = others
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        out["gather_ms"] = round(float(np.mean(gather_ms)), 3)       # rank 0, mean per timed step (at N = 1: the copy into frame order)
+        out["rmse_vs_cpu"] = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(flat, W, H, spp_frame)
-            out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+            cb, rows_j, cpu_sums = cpu_baseline(flat, W, H, spp_frame)
+            out["cpu_baseline"] = cb
+            out["cpu_baseline"]["gpu_over_cpu"] = round(value / cb["value"], 1)
+            # the RMSE half of the metric, in the same run: the rows Oracle A has just rendered against the same rows of
+            # the frame the last timed step left on the GPU (exact sums and resolved RGBA8 bytes)
+            idx = torch.as_tensor(rows_j, device=dev)
+            gpu_rows = step.last_full.index_select(0, idx).cpu().numpy().view(np.uint64)
+            gpu_rgba = d_rgba.index_select(0, (H - 1) - idx).cpu().numpy()          # flipped frame: image row y = H-1-j
+            par = rmse_vs_cpu(gpu_rows, gpu_rgba, cpu_sums, spp_frame)
+            out["rmse_vs_cpu"] = par["rmse"]
+            out["rmse_gate"] = 1e-4
+            out["parity_vs_cpu"] = {
+                **par, "rows": int(len(rows_j)), "row_stride": int(rows_j[1] - rows_j[0]) if len(rows_j) > 1 else 0,
+                "pixels": int(len(rows_j)) * W, "samples": int(len(rows_j)) * W * spp_frame,
+                "definition": "sqrt(mean over pixels and channels of (GPU_mean - CPU_mean)^2) on linear radiance means "
+                              "(main.rs:135-137: pixel_color / spp, before gamma); CPU = Oracle A (literal f64 "
+                              "restatement), same seed, same rows of the frame timed above; rgba8 = Color::to_rgba bytes",
+            }
         print(json.dumps(out), flush=True)
 
     renderer.close()

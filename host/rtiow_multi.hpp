@@ -40,6 +40,7 @@ inline int render_sharded(const std::vector<int> &devices, bool force_rccl, cons
                           std::string *err)
 {
     const int n = (int)devices.size();
+    if (n == 0) { *err = "empty device list"; return 1; }
     const std::set<int> uniq(devices.begin(), devices.end());
     const bool distinct = (int)uniq.size() == n;
     const bool use_rccl = (distinct && n > 1) || (force_rccl && distinct);
@@ -51,19 +52,42 @@ inline int render_sharded(const std::vector<int> &devices, bool force_rccl, cons
 
     std::vector<ShardJob> jobs(n);
     std::vector<ncclComm_t> comms(n, nullptr);
-    if (use_rccl) {
-        const ncclResult_t r = ncclCommInitAll(comms.data(), n, devices.data());
-        if (r != ncclSuccess) { *err = std::string("ncclCommInitAll: ") + ncclGetErrorString(r); return 1; }
-    }
     uint64_t *d_staging = nullptr;                                      // root: the gathered parts [n][pad_rows][W][3]
+    uint64_t *d_full = nullptr;
+    uint8_t *d_rgba = nullptr;
+    // ONE exit path: whatever was created is released, on success and on every error return
+    auto cleanup = [&]() {
+        for (int k = 0; k < n; ++k) {
+            ShardJob &J = jobs[k];
+            if (J.ctx || J.d_fix || J.stream) (void)hipSetDevice(J.device);
+            if (J.stream) { (void)hipStreamSynchronize(J.stream); }
+            if (J.d_fix) (void)hipFree(J.d_fix);
+            if (J.stream) (void)hipStreamDestroy(J.stream);
+            if (J.ctx) rt_destroy(J.ctx);
+            if (comms[k]) ncclCommDestroy(comms[k]);
+            J.d_fix = nullptr; J.stream = nullptr; J.ctx = nullptr; comms[k] = nullptr;
+        }
+        if (d_full || d_rgba || d_staging) (void)hipSetDevice(devices[0]);
+        (void)hipFree(d_full); (void)hipFree(d_rgba); (void)hipFree(d_staging);
+        d_full = nullptr; d_rgba = nullptr; d_staging = nullptr;
+    };
+    auto bail = [&](const std::string &msg) { *err = msg; cleanup(); return 1; };
     auto hip_ok = [](hipError_t e, const char *what, std::string *msg) {
         if (e == hipSuccess) return true;
         *msg = std::string(what) + ": " + hipGetErrorString(e);
         return false;
     };
-    if (!hip_ok(hipSetDevice(devices[0]), "hipSetDevice", err)) return 1;
-    if (use_rccl && !hip_ok(hipMalloc((void **)&d_staging, (size_t)n * pad_words * sizeof(uint64_t)), "hipMalloc staging", err)) return 1;
+    std::string msg;
+    if (use_rccl) {
+        const ncclResult_t r = ncclCommInitAll(comms.data(), n, devices.data());
+        if (r != ncclSuccess) return bail(std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+    }
+    if (!hip_ok(hipSetDevice(devices[0]), "hipSetDevice", &msg)) return bail(msg);
+    if (use_rccl && !hip_ok(hipMalloc((void **)&d_staging, (size_t)n * pad_words * sizeof(uint64_t)), "hipMalloc staging", &msg)) return bail(msg);
 
+    // ---- phase 1: every shard, on its own host thread: context, scene, buffers, the render launch (main.rs:122-136).
+    // No collective in this phase: a shard that fails here (bad device, out of memory, a rejected scene) simply
+    // reports, and no other shard is left waiting inside a gather for it.
     auto work = [&](int k) {
         ShardJob &J = jobs[k];
         J.device = devices[k];
@@ -80,27 +104,38 @@ inline int render_sharded(const std::vector<int> &devices, bool force_rccl, cons
         if (!hip_ok(hipStreamCreateWithFlags(&J.stream, hipStreamNonBlocking), "hipStreamCreate", &J.err)) return;
         if (!hip_ok(hipMalloc((void **)&J.d_fix, pad_words * sizeof(uint64_t)), "hipMalloc", &J.err)) return;
         if (!hip_ok(hipMemsetAsync(J.d_fix, 0, pad_words * sizeof(uint64_t), J.stream), "hipMemsetAsync", &J.err)) return;
-        if ((rc = rt_render_device(J.ctx, &cam, &p, J.d_fix, J.stream))) return fail("rt_render_device");   // main.rs:122-136
-        if (use_rccl) {
-            // THE collective of the path: every rank sends its padded rows, rank 0 receives all of them
-            const ncclResult_t r = ncclGather(J.d_fix, d_staging, pad_words, ncclUint64, 0, comms[k], J.stream);
-            if (r != ncclSuccess) { J.err = std::string("ncclGather: ") + ncclGetErrorString(r); return; }
-        }
-        if (!hip_ok(hipStreamSynchronize(J.stream), "hipStreamSynchronize", &J.err)) return;
-        if ((rc = rt_last_stats(J.ctx, &J.stats))) return fail("rt_last_stats");
+        if ((rc = rt_render_device(J.ctx, &cam, &p, J.d_fix, J.stream))) return fail("rt_render_device");
     };
-    std::vector<std::thread> threads;
-    for (int k = 0; k < n; ++k) threads.emplace_back(work, k);
-    for (auto &t : threads) t.join();
-    for (const ShardJob &J : jobs) if (!J.err.empty()) { *err = J.err; return 1; }
+    {
+        std::vector<std::thread> threads;
+        for (int k = 0; k < n; ++k) threads.emplace_back(work, k);
+        for (auto &t : threads) t.join();
+    }
+    for (const ShardJob &J : jobs) if (!J.err.empty()) return bail(J.err);
+
+    // ---- phase 2 (only when EVERY shard has launched): THE collective of the path -- every rank sends its padded
+    // rows behind its render on its own stream, rank 0 receives all of them.  One thread drives all communicators
+    // of this process, so the calls form one group (ncclGroupStart/End).
+    if (use_rccl) {
+        ncclResult_t r = ncclGroupStart();
+        for (int k = 0; k < n && r == ncclSuccess; ++k)
+            r = ncclGather(jobs[k].d_fix, d_staging, pad_words, ncclUint64, 0, comms[k], jobs[k].stream);
+        const ncclResult_t e = ncclGroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) return bail(std::string("ncclGather: ") + ncclGetErrorString(r));
+    }
+    for (int k = 0; k < n; ++k) {
+        ShardJob &J = jobs[k];
+        if (!hip_ok(hipSetDevice(J.device), "hipSetDevice", &msg)) return bail(msg);
+        if (!hip_ok(hipStreamSynchronize(J.stream), "hipStreamSynchronize", &msg)) return bail(msg);
+        if (rt_last_stats(J.ctx, &J.stats)) return bail(std::string("rt_last_stats (shard ") + std::to_string(k) + "): " + rt_last_error());
+    }
 
     // rank 0: rows back into image order.  Shard k owns tiles k, k+n, ...: tile t of the image is local tile
     // t / n of shard t % n, so one strided copy per (shard, row within a tile) rebuilds the frame.
-    uint64_t *d_full = nullptr;
-    uint8_t *d_rgba = nullptr;
-    if (!hip_ok(hipSetDevice(devices[0]), "hipSetDevice", err)) return 1;
-    if (!hip_ok(hipMalloc((void **)&d_full, (size_t)H * row_words * sizeof(uint64_t)), "hipMalloc frame", err)) return 1;
-    if (!hip_ok(hipMalloc((void **)&d_rgba, (size_t)H * W * 4), "hipMalloc rgba", err)) return 1;
+    if (!hip_ok(hipSetDevice(devices[0]), "hipSetDevice", &msg)) return bail(msg);
+    if (!hip_ok(hipMalloc((void **)&d_full, (size_t)H * row_words * sizeof(uint64_t)), "hipMalloc frame", &msg)) return bail(msg);
+    if (!hip_ok(hipMalloc((void **)&d_rgba, (size_t)H * W * 4), "hipMalloc rgba", &msg)) return bail(msg);
     hipStream_t s0 = jobs[0].stream;
     const size_t row_bytes = row_words * sizeof(uint64_t);
     for (int k = 0; k < n; ++k) {
@@ -109,13 +144,13 @@ inline int render_sharded(const std::vector<int> &devices, bool force_rccl, cons
             const int lt = t / n;                                        // local tile of shard k
             const int lo = t * T, cnt = std::min(T, H - lo);
             if (!hip_ok(hipMemcpyAsync(d_full + (size_t)lo * row_words, src + (size_t)lt * T * row_words,
-                                       (size_t)cnt * row_bytes, hipMemcpyDeviceToDevice, s0), "hipMemcpyAsync rows", err)) return 1;
+                                       (size_t)cnt * row_bytes, hipMemcpyDeviceToDevice, s0), "hipMemcpyAsync rows", &msg)) return bail(msg);
         }
     }
     long long spp_total = base.spp;
-    if (rt_resolve_rgba8_device(jobs[0].ctx, d_full, W, H, spp_total, 1, d_rgba, s0)) { *err = rt_last_error(); return 1; }
-    if (!hip_ok(hipMemcpyAsync(rgba_out, d_rgba, (size_t)H * W * 4, hipMemcpyDeviceToHost, s0), "hipMemcpyAsync rgba", err)) return 1;
-    if (!hip_ok(hipStreamSynchronize(s0), "hipStreamSynchronize", err)) return 1;
+    if (rt_resolve_rgba8_device(jobs[0].ctx, d_full, W, H, spp_total, 1, d_rgba, s0)) return bail(rt_last_error());
+    if (!hip_ok(hipMemcpyAsync(rgba_out, d_rgba, (size_t)H * W * 4, hipMemcpyDeviceToHost, s0), "hipMemcpyAsync rgba", &msg)) return bail(msg);
+    if (!hip_ok(hipStreamSynchronize(s0), "hipStreamSynchronize", &msg)) return bail(msg);
 
     if (stats_out) {
         *stats_out = jobs[0].stats;
@@ -125,14 +160,7 @@ inline int render_sharded(const std::vector<int> &devices, bool force_rccl, cons
             stats_out->kernel_ms = std::max(stats_out->kernel_ms, jobs[k].stats.kernel_ms);
         }
     }
-    (void)hipFree(d_full); (void)hipFree(d_rgba); (void)hipFree(d_staging);
-    for (int k = 0; k < n; ++k) {
-        (void)hipSetDevice(jobs[k].device);
-        (void)hipFree(jobs[k].d_fix);
-        if (jobs[k].stream) (void)hipStreamDestroy(jobs[k].stream);
-        rt_destroy(jobs[k].ctx);
-        if (comms[k]) ncclCommDestroy(comms[k]);
-    }
+    cleanup();
     return 0;
 }
 

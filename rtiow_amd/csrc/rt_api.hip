@@ -58,7 +58,7 @@ struct rt_context {
     uint32_t *d_slot_orig = nullptr;   // MODE 5: [slots] list index of the sphere in each column of the table
     int n_global = 0;              // MODE 5: tiles [0, n_global) are scanned for every ray; the rest are grid cells
     int grid_dim = 0;              // MODE 5: cells per side of the xz grid (0: no grid, every tile is scanned)
-    float grid[8] = {};            // x0, z0, 1/cell, x1, z1, y lo, y hi, pad (rt_device.hpp, mark_grid_cells)
+    float grid[8] = {};            // x0, z0, 1/cell, x1, z1, y lo, y hi, pad (rt_device.hpp, grid_cells)
     float scene_scale = 0.0f;      // MODE 5: KParams::scene_scale
 #ifdef RTIOW_CROSSCHECK_MODES
     float *d_bmat = nullptr;       // [tiles][64] MFMA B operand of the filter
@@ -372,12 +372,19 @@ TileLayout tile_layout(const rt_sphere *spheres, int n, const char *never)
             z0 = std::min(z0, spheres[i].center[2]); z1 = std::max(z1, spheres[i].center[2]);
         }
         const double extent = std::max(x1 - x0, z1 - z0);
+        // The kernel finds cells with f32 arithmetic on (coordinate - x0) * (1 / cell): the grid exists only while that
+        // is meaningful -- a positive extent below 1e15 (coordinates up to 1e15 are legal, so extents up to 2e15 occur)
+        // whose cell size has a finite, normal f32 reciprocal.  extent == 0 (every small sphere above the same point):
+        // ONE cell of size 1.  Anything else: no grid, every tile scanned, columns in list order.
+        const bool one_cell = extent == 0.0;
+        const bool grid_ok = one_cell || (extent > 0.0 && extent < 1e15);
+        if (grid_ok) {
         // cells(G): the spheres of each cell of a G x G grid, and what does not go into a cell
         std::vector<std::vector<int>> cells;
         std::vector<int> global;
         double cell = 1.0;
         auto assign = [&](int G, bool keep) -> int {       // -> number of global tiles
-            cell = (extent > 0.0 && extent < 1e15) ? extent / G : 1.0;
+            cell = one_cell ? 1.0 : extent / G;
             std::vector<int> count((size_t)G * G, 0);
             if (keep) { cells.assign((size_t)G * G, {}); global.clear(); }
             size_t n_glob = 0;
@@ -399,7 +406,7 @@ TileLayout tile_layout(const rt_sphere *spheres, int n, const char *never)
         // The grid's resolution: a wave scans the global tiles plus the cells its 64 rays touch, and rays are lines --
         // the cells touched grow like G (measured on the book scenes: about 1.4 G - 1.6 of G x G), while coarse cells
         // overflow into global tiles.  Take the G with the smallest  global tiles + 1.4 G.
-        int G = env_int("RTIOW_GRID_DIM", 0);
+        int G = one_cell ? 1 : env_int("RTIOW_GRID_DIM", 0);
         if (G <= 0) {
             double best = INFINITY;
             for (int g = 1; g <= 42; ++g) {
@@ -420,7 +427,8 @@ TileLayout tile_layout(const rt_sphere *spheres, int n, const char *never)
                 pad = std::max(pad, r);
             }
         const int n_global = (int)((global.size() + 31) / 32);
-        if ((size_t)(n_global + G * G) * 32 <= 65536 && n_global <= 48 && ylo <= yhi) {
+        const float inv_cell = (float)(1.0 / cell);
+        if (std::isnormal(inv_cell) && (size_t)(n_global + G * G) * 32 <= 65536 && n_global <= 48 && ylo <= yhi) {
             L.grid_dim = G; L.n_global = n_global;
             slot_of.assign((size_t)(n_global + G * G) * 32, -1);
             for (size_t k = 0; k < global.size(); ++k) slot_of[k] = global[k];
@@ -431,7 +439,7 @@ TileLayout tile_layout(const rt_sphere *spheres, int n, const char *never)
             L.grid[0] = down(x0); L.grid[1] = down(z0);
             // the kernel turns a coordinate into a cell with THESE f32 values; rounding 1/cell either way only
             // shifts cell borders by ~1e-7 cells, which the kernel's own margin (1e-3 cells) covers
-            L.grid[2] = (float)(1.0 / cell);
+            L.grid[2] = inv_cell;
             L.grid[3] = up(x0 + G * cell); L.grid[4] = up(z0 + G * cell);
             L.grid[5] = down(ylo); L.grid[6] = up(yhi); L.grid[7] = up(pad);
             // the kernel's error margins are relative to the size of what a ray can reach inside the grid's box
@@ -439,6 +447,7 @@ TileLayout tile_layout(const rt_sphere *spheres, int n, const char *never)
                               std::max(std::fabs(z0), std::fabs(z0 + G * cell)) + pad;
             L.scale = (float)gs * 1.0001f;
         }
+        }   // grid_ok
     }
     if (L.grid_dim == 0) {                              // no grid: the columns in list order, every tile scanned
         slot_of.assign((size_t)((filtered.empty() ? 0 : filtered.back() + 1) + 31) / 32 * 32, -1);

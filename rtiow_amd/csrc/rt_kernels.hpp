@@ -410,17 +410,36 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
         int hit = -1;
         uint32_t n_cand = 0, n_roots = 0;                           // this bounce, this lane
         const double a = length_squared(d);                         // sphere.rs:20
-        // sphere.rs:16-34 for sphere idx, exactly as the reference computes it
-        auto exact_test = [&](int idx) {
+        // sphere.rs:16-34 for sphere idx, exactly as the reference computes it.
+        // ORDERED (std::true_type): the caller visits the spheres in LIST order and this is HittableList::hit's loop body
+        // as written (mod.rs:61-67 with sphere.rs:29-33's `root < t_min || t_max < root`), degenerate values included:
+        // a NaN root fails neither comparison and is ACCEPTED, after which closest_so_far is NaN and every later sphere
+        // with a root >= t_min is accepted too -- what the reference does with a zero-length, NaN or infinite direction.
+        // Used wherever the visit IS in list order: the no-filter and VALU-filter modes, and the rays outside the
+        // filter's analysed range (which is where every such direction ends up).
+        auto exact_test = [&](int idx, auto ordered) {
             const double4 g = *reinterpret_cast<const double4 *>(geo + 4 * (size_t)idx);
             const D3 oc = o - mk(g.x, g.y, g.z);
             const double half_b = dot(oc, d);
             const double c = length_squared(oc) - g.w;              // g.w = radius*radius
             const double disc = half_b * half_b - a * c;
             if (disc < 0.0) return;                                 // sphere.rs:25
+            if constexpr (decltype(ordered)::value) {
+                if (DIAG && !(half_b > 0.0 && c > 0.0)) n_roots++;  // (counted like the other form: where that one takes a root)
+                const double sq = __builtin_sqrt(disc);
+                double r = (-half_b - sq) / a;                      // sphere.rs:28-34
+                if (r < t_min || closest < r) {
+                    r = (-half_b + sq) / a;
+                    if (r < t_min || closest < r) return;
+                }
+                closest = r;                                        // mod.rs:63-64
+                hit = idx;
+                return;
+            }
             // Both roots are <= 0 < t_min when the origin is outside (c > 0) and the
             // sphere lies behind the ray (half_b > 0): sqrt(disc) <= half_b, so the
             // reference's two range tests (sphere.rs:29-33) both fail.  Skip the sqrt.
+            // (Not for a == 0: there the far root is 0/0, which the reference accepts -- such rays take the ORDERED form.)
             if (half_b > 0.0 && c > 0.0) return;
             if (DIAG) n_roots++;
             const double sqrtd = __builtin_sqrt(disc);
@@ -443,7 +462,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
         auto test_list = [&](int cnt) {
             // trip count = longest list among the active lanes (exec-masked vote)
             for (int k = 0; __any(k < cnt); ++k) {
-                if (k < cnt) { if (DIAG) n_cand++; exact_test((int)cand[k][tid]); }
+                if (k < cnt) { if (DIAG) n_cand++; exact_test((int)cand[k][tid], std::true_type{}); }
             }
         };
 
@@ -650,7 +669,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
 
             if constexpr (TUBE) {
                 if (alive)
-                    for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e]); }
+                    for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e], std::false_type{}); }
                 const bool scan = alive;
                 const unsigned long long scan_mask = __ballot(scan);
                 if (scan_mask != 0ull) {
@@ -661,8 +680,12 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     tube_a_words(T, w);
                     tube_stage_operands(reinterpret_cast<uint4 *>(bits_w), lane, w, A);
                 }
-                // outside the analysed range: everything is tested exactly
-                if (scan && !T.sane) for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i); }
+                // outside the analysed range (zero, NaN and infinite directions are): HittableList::hit as written, over
+                // the whole list in list order (what the always-exact list and the pool find for this ray is a subset of it)
+                if (scan && !T.sane) {
+                    closest = __builtin_inf(); hit = -1;
+                    for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i, std::true_type{}); }
+                }
                 typedef float f32x16 __attribute__((ext_vector_type(16)));
                 const int ntt = nt >> 1;                    // tiles of 32 spheres; the tables hold ntt + 1
                 const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
@@ -801,8 +824,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 RT_STAMP(5);
                 // waves in the tile loop issue ahead of their SIMD partners: the matrix pipe is fed sooner and the other
                 // waves' vector work fills the time the MFMAs take (measured: -1.4 % on configs[1])
-                __builtin_amdgcn_s_setprio(1);
                 for (int t0 = 0; t0 < n_list; t0 += kSeg / 2) {
+                    __builtin_amdgcn_s_setprio(1);              // (raised per segment: an empty list never raises it)
                     const int nwords = min(kSeg / 2, n_list - t0);          // one bitmap word per 32-sphere tile
                     for (int w = 0; w < nwords; ++w) bits_w[w * 64 + lane] = 0u;
                     // the segment's tiles (and two more for the look-ahead), one per lane
@@ -846,7 +869,6 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     RT_STAMP(6);
                     __builtin_amdgcn_s_setprio(0);
                     enumerate(t0, nwords);
-                    if (t0 + kSeg / 2 < n_list) __builtin_amdgcn_s_setprio(1);
                 }
                 finish_pool();
                 }   // scan_mask != 0
@@ -861,9 +883,12 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     lifted_stage_operands(reinterpret_cast<uint4 *>(bits_w), lane, w, A);
                 }
                 if (alive) {
-                    for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e]); }
+                    for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e], std::false_type{}); }
                     // outside the analysed range: everything is tested exactly
-                    if (!L.sane) for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i); }
+                    if (!L.sane) {
+                        closest = __builtin_inf(); hit = -1;
+                        for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i, std::true_type{}); }
+                    }
                 }
                 // B operands: 2 KB per tile, lane l reads 16 bytes at 16 l of each half; a raw buffer
                 // load takes the lane part from a VGPR that never changes and the tile part from
@@ -959,9 +984,12 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 check_half(h, Dv, kp, trel);
             };
             if (alive) {
-                for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e]); }
+                for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e], std::false_type{}); }
                 // outside the analysed range: everything is tested exactly
-                if (!f.sane) for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i); }
+                if (!f.sane) {
+                    closest = __builtin_inf(); hit = -1;
+                    for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i, std::true_type{}); }
+                }
             }
             RT_STAMP(5);
             for (int seg0 = 0; seg0 < nt; seg0 += kSegTiles) {
@@ -998,7 +1026,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
         RT_STAMP(2);
         if (alive && !MATRIX) {
             if (MODE == 0) {
-                for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i); }
+                for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i, std::true_type{}); }
             } else {
                 const RayFilter f = make_filter(o, d);
                 int cnt = 0;

@@ -115,13 +115,11 @@ def test_cfg2_device_buffers_accumulate_flag(renderer, book1_flat, cfg2):
     assert np.array_equal(d_sum.cpu().numpy(), want_sum)
 
 
-def test_work_decomposition_does_not_change_results(book1_flat, cfg2):
-    """Samples per work item, the single-sample phase at the end of the launch, items per reservation
-    and blocks per CU are scheduling knobs only."""
+def test_blocks_per_cu_does_not_change_the_full_frame(book1_flat, cfg2):
+    """Blocks per CU is a scheduling knob only (the knobs that select other code paths -- grid resolution, no grid, LDS
+    block sums off -- are compared with the ORACLE in test_gpu_oracle_holes.py; here the full configs[1] frame)."""
     w, h, spp, fix, st = cfg2
-    for env in ({"RTIOW_CHUNK": "1"}, {"RTIOW_CHUNK": "7", "RTIOW_BLOCKS_PER_CU": "2"}, {"RTIOW_CHUNK": "100"},
-                {"RTIOW_TAIL_SPP": "0"}, {"RTIOW_TAIL_SPP": "3", "RTIOW_CHUNK": "5"},
-                {"RTIOW_TAIL_SPP": "1000000", "RTIOW_ITEM_BLOCK": "64"}, {"RTIOW_TAIL_SPP": "37", "RTIOW_ITEM_BLOCK": "1000"}):
+    for env in ({"RTIOW_BLOCKS_PER_CU": "1"}, {"RTIOW_BLOCKS_PER_CU": "3", "RTIOW_RING_MIN_SPP": "101"}):
         os.environ.update(env)
         try:
             r = rt.Renderer(0)
@@ -133,6 +131,7 @@ def test_work_decomposition_does_not_change_results(book1_flat, cfg2):
                 os.environ.pop(k)
         assert np.array_equal(got, fix), env
         assert st2["rays_traced"] == st["rays_traced"]
+        assert st2["grid_blocks"] == 256 * int(env["RTIOW_BLOCKS_PER_CU"])
 
 
 def test_gpu_reproduces_the_reference_png_sky_rows(renderer, book1_flat):

@@ -55,7 +55,16 @@ def scene_cases():
     # every centre the same point
     same = spheres(np.tile([[1.0, 2.0, 3.0]], (100, 1)), np.linspace(0.1, 0.3, 100))
     small = rt.random_scene(1, grid=(-3, 3)).flatten()       # <= 64 spheres go through the filter: no grid
-    return {"book": book, "tenk": tenk, "cloud": cloud, "clusters": clusters, "line": line, "same": same, "small": small}
+    # legal coordinates (|x| < 1e15, rt_upload_scene) whose xz extent is beyond what f32 cell arithmetic can carry: two
+    # groups around x = -9e14 and x = +9e14 (extent 1.8e15) -- the grid must be OFF, not a box that misses most spheres
+    wide = spheres(np.concatenate([rng.uniform(-5, 5, (100, 3)) + (-9e14, 0, 0), rng.uniform(-5, 5, (100, 3)) + (9e14, 0, 0)]),
+                   np.full(200, 0.2))
+    # one axis huge (x spans 1.6e14, inside the limit), the other ten units wide: the grid stays on and must still hold its spheres
+    huge_x = spheres(np.stack([rng.uniform(-8e13, 8e13, 300), rng.uniform(0, 1, 300), rng.uniform(-5, 5, 300)], 1), np.full(300, 0.2))
+    # both axes huge but inside the limit: a real G x G grid at the edge of what the f32 cell arithmetic carries
+    huge_xz = spheres(np.stack([rng.uniform(-8e13, 8e13, 2000), rng.uniform(0, 1, 2000), rng.uniform(-8e13, 8e13, 2000)], 1), np.full(2000, 0.2))
+    return {"book": book, "tenk": tenk, "cloud": cloud, "clusters": clusters, "line": line, "same": same, "small": small,
+            "wide": wide, "huge_x": huge_x, "huge_xz": huge_xz}
 
 
 CASES = scene_cases()
@@ -73,12 +82,14 @@ def test_every_filtered_sphere_has_one_column_and_cells_hold_what_the_kernel_ass
     missing = np.setdiff1d(np.arange(n), used)
     r = np.abs(flat["radius"])
     assert len(missing) <= 8 and np.all(r[missing] > 8 * np.median(r))
-    if name == "small":
+    if name in ("small", "wide"):
         assert G == 0
+    if name == "same":
+        assert G == 1
     if G == 0:
         assert np.array_equal(used, np.sort(used)) and np.all(slot_of[used] == used)      # columns in list order
         return
-    assert name in ("same", "line") or G > 1
+    assert name in ("same", "line", "huge_x") or G > 1        # (a 1-D distribution of spheres: one cell can be the cheapest grid)
     assert len(slot_of) == 32 * (n_global + G * G) and 0 <= n_global <= 48
     x0, z0, inv, x1, z1, ylo, yhi, pad = [float(v) for v in g]
     for t in range(n_global, n_global + G * G):

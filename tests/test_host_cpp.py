@@ -68,3 +68,27 @@ def test_cpp_sharded_render_equals_the_single_context_image(tmp_path, extra):
     r = subprocess.run([_cli(), *size, *extra, "--out", sharded], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert open(single, "rb").read() == open(sharded, "rb").read()
+
+
+@pytest.mark.parametrize("devices", ["0,99", "99", "0,0,99"])
+def test_cpp_sharded_render_with_a_bad_device_reports_instead_of_blocking(tmp_path, devices):
+    """host/rtiow_multi.hpp: a shard that cannot start (no such device) makes render_sharded return an error -- every
+    shard finishes its launch phase before any enters the gather, so no rank is left waiting in a collective, and the
+    single exit path frees what the others had created.  Runs with or without a GPU (without one every shard fails)."""
+    r = subprocess.run([_cli(), "--width", "64", "--height", "36", "--spp", "2", "--devices", devices, "--out", str(tmp_path / "x.ppm")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "render_sharded failed" in r.stderr
+    assert not os.path.exists(str(tmp_path / "x.ppm"))
+
+
+@pytest.mark.gpu
+def test_cpp_sharded_render_with_a_rejected_scene_reports_instead_of_blocking(tmp_path):
+    """The same on the RCCL path with a live communicator: rt_upload_scene rejects the scene (unknown material kind) in
+    the launch phase of every shard; the process must return the error, not hang in ncclGather."""
+    bad = rt.random_scene(1).flatten()
+    bad["kind"][5] = 9
+    path = str(tmp_path / "bad.bin")
+    bad.tofile(path)
+    r = subprocess.run([_cli(), "--scene", path, "--width", "64", "--height", "36", "--spp", "2", "--devices", "0", "--force-rccl",
+                        "--out", str(tmp_path / "x.ppm")], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "unknown material kind" in r.stderr

@@ -4,7 +4,7 @@ profiles/<tag>_rocprofv3_<cfg>.json, profiles/<tag>_kernel_stats_<cfg>.csv and p
 kernel sources they were measured on -- bench.py nulls them when the sources have changed)."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 import bench  # noqa: E402  (kernel_source_sha)
@@ -52,6 +52,13 @@ for cfg, shape in CONFIGS.items():
                     "rocprof_avg_kernel_ms": avg_ns / 1e6,
                     "hbm_bytes_per_launch": fetch + write,
                     "mfma_insts_per_launch": pm.get("SQ_INSTS_MFMA"), "valu_insts_per_launch": pm.get("SQ_INSTS_VALU"),
-                    "simd_cycles_per_launch": cycles, "valu_busy": valu_busy})
+                    "simd_cycles_per_launch": cycles, "valu_busy": valu_busy,
+                    # instruction classes for the hardware-derived issue peak (bench.py, roofline.peak) and the overhead accounting
+                    "f64_addmulfma_insts_per_launch": (sum(pm.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"))
+                                                       if "SQ_INSTS_VALU_FMA_F64" in pm else None),
+                    "trans_f32_insts_per_launch": pm.get("SQ_INSTS_VALU_TRANS_F32"),
+                    "salu_insts_per_launch": pm.get("SQ_INSTS_SALU"), "branch_insts_per_launch": pm.get("SQ_INSTS_BRANCH"),
+                    "lds_bank_conflict_share": (pm["SQ_LDS_BANK_CONFLICT"] / pm["SQ_LDS_IDX_ACTIVE"]
+                                                if pm.get("SQ_LDS_IDX_ACTIVE") else None)})
     print(cfg, json.dumps(out["kernel_stats"][0]), out["hbm_bytes_per_launch"], out.get("effective_clock_GHz"), valu_busy)
 json.dump({"entries": entries}, open(os.path.join(root, "profiles", "pmc_replay.json"), "w"), indent=1)
