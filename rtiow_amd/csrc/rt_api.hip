@@ -840,6 +840,14 @@ extern "C" int rt_debug_phase_cycles(rt_context *ctx, unsigned long long out[8])
     RT_HIP(hipMemcpy(out, ctx->d_stats + 8, 64, hipMemcpyDeviceToHost));
     return RT_OK;
 }
+extern "C" int rt_debug_phase_cycles16(rt_context *ctx, unsigned long long out[16])      // the 8 above + the finer split at stats[80..87]
+{
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipEventSynchronize(ctx->ev1));
+    RT_HIP(hipMemcpy(out, ctx->d_stats + 8, 64, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(out + 8, ctx->d_stats + 80, 64, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
 #endif
 
 int rt_fix_to_f32_device(rt_context *ctx, const void *d_fix, int64_t count, void *d_out_f32, void *stream_v)

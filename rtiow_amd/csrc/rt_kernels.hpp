@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
 #ifdef RT_PHASE_STAMPS
     // Diagnostic build only (never the shipped library): wave-time spent per phase, summed
     // into stats[8..15].  The stamps serialise the phases; read the SHARES, not the total.
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #define RT_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); \
                          __builtin_amdgcn_s_waitcnt(0); ph[k] += tn_ - tprev; tprev = tn_; } while (0)
 #define RT_COUNT(k) do { } while (0)
@@ -283,6 +283,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             const unsigned long long m = __ballot(want);
             if (m == 0ull) break;
             if (q_count == 0u) {
+                RT_STAMP(0);
                 // ---- (b) refill: main.rs:131-134 + camera.rs:47-54 for the next (up to) 64 items of the block ----
                 // A wave reserves kItemBlock consecutive items with ONE returning atomic on the device-wide counter:
                 // one word sustains only ~88 dequeues/us chip-wide (MI355X_MICROARCH.md, row "dequeue").
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 blk_next += n_gen;
                 q_head = 0u; q_count = n_gen;
                 __builtin_amdgcn_wave_barrier();
+                RT_STAMP(8);
             }
             const uint32_t r = rank_below(m);
             if (want && r < q_count) {
@@ -384,6 +386,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             const uint32_t took = cnt < q_count ? cnt : q_count;
             q_head += took; q_count -= took;
         }
+        RT_STAMP(0);
         if (fresh) {                                                // camera.rs:47-54
             const double lx = u11(lens_wx), ly = u11(lens_wy);
             const D3 cam_origin = ld3(P.cam.origin);
@@ -396,8 +399,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             alive = true;
         }
 
-        RT_STAMP(0);
-        RT_STAMP(1);
+        RT_STAMP(9);
         // ---- (c) every lane of the wave is out of work: done ------------------
         const unsigned long long alive_mask = __ballot(alive);
         if (alive_mask == 0ull) break;
@@ -570,6 +572,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             bidx_w[lane] = 0u;                                          // sphere index + 1; 0 = none
             uint32_t pool_n = 0, pool_done = 0;                         // wave-uniform
             auto pool_round = [&]() {
+                RT_STAMP(10);
                 RT_COUNT(5);
                 const uint32_t e_i = pool_done + (uint32_t)lane;
                 const bool act = e_i < pool_n;
@@ -618,6 +621,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 if (has_root && best_w[r] == key) atomicMax(&bidx_w[r], (unsigned)idx + 1u);
                 __builtin_amdgcn_wave_barrier();
                 pool_done = min(pool_done + 64u, pool_n);
+                RT_STAMP(2);
             };
             // owners push the candidates of segment seg0 (ascending sphere order); rounds run as the ring fills
             // MODE 5: the tiles this pass scans -- every tile of the table in turn, or the list behind the bitmap words
@@ -657,6 +661,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             };
             // after the last segment: drain the ring, then every owner takes its minimum
             auto finish_pool = [&]() {
+                RT_STAMP(10);
                 while (pool_done < pool_n) pool_round();
                 const unsigned int hb = bidx_w[lane];
                 if (alive && hb != 0u) {
@@ -761,8 +766,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 };
                 if (SMALLGRID || P.grid_dim > 0) {
                     int ix0 = 0, nx = 0, iz0 = 0, nz = 0, cnt = 0;
+                    GridSeg seg;
                     RT_STAMP(5);
-                    if (scan && T.sane) cnt = grid_cells(o, d, P.grid, P.grid_dim, P.scene_scale, ix0, nx, iz0, nz);
+                    if (scan && T.sane) cnt = grid_cells(o, d, P.grid, P.grid_dim, P.scene_scale, ix0, nx, iz0, nz, SMALLGRID ? nullptr : &seg);
                     RT_STAMP(7);
                     const int gcells = P.grid_dim * P.grid_dim;
                     if (SMALLGRID || P.n_global + gcells <= 64) {
@@ -793,10 +799,14 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                         unsigned long long *tm = reinterpret_cast<unsigned long long *>(bits_w);   // (512 B of the bitmap area, free until the tile loop)
                         tm[lane] = 0ull;
                         __builtin_amdgcn_wave_barrier();
-                        const unsigned long long run = ((1ull << nx) - 1ull) << ix0;    // nx + ix0 <= grid_dim <= 42
+                        // row by row: the columns of the part of the clipped piece that lies in the row's band (grid_row_run)
                         if (cnt == 0) nz = 0;
                         for (int k = 0; __any(k < nz); ++k)
-                            if (k < nz) atomicOr(&tm[iz0 + k], run);
+                            if (k < nz) {
+                                int rx0, rnx;                                               // rnx + rx0 <= grid_dim <= 42
+                                grid_row_run(seg, P.grid_dim, iz0 + k, rx0, rnx);
+                                atomicOr(&tm[iz0 + k], ((1ull << rnx) - 1ull) << rx0);
+                            }
                         __builtin_amdgcn_wave_barrier();
                         unsigned long long mw = tm[lane];
                         const int mine = __builtin_popcountll(mw);
@@ -1104,6 +1114,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 // really made -- the Dialectric's reflectance draw.  One wave-level call, not two.
                 U4 w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
                 w_first = w.x;
+                RT_STAMP(11);
                 if (kind != RT_KIND_DIALECTRIC) {
                     // vec3.rs:37-45: redraw until |p|^2 < 1 -- on the integers behind the three uniforms, where the
                     // reference's f64 comparison is exact (see unit_sphere_accepts); converted once, after the loop.
@@ -1149,6 +1160,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             // Every branch normalises exactly one vector (vec3.rs:107-109: v * (1/sqrt(v.v))): the
             // sky and Dialectric take unit(d), Lambertian unit(sample), Metal unit(reflect(d,n)).
             // One shared f64 sqrt + divide for the whole wave instead of one per branch.
+            RT_STAMP(12);
             D3 V = d;
             if (kind == RT_KIND_LAMBERTIAN) V = sp;
             if (kind == RT_KIND_METAL) V = reflect(d, nrm);
@@ -1202,6 +1214,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 radiance = L;
             }
         }
+        RT_STAMP(13);
         // ---- (f) finished samples -> their block's sums (LDS) or, without a ring entry, the frame buffer ----
         {
             // age of this lane's block among the wave's blocks (0 = the current one); blocks of age >= kRingDepth have
@@ -1268,7 +1281,10 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
         atomicMax(P.stats + 11, ~t_wave_start); atomicAdd(P.stats + 12, 1ull);
     }
 #elif defined(RT_PHASE_STAMPS)
-    if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(P.stats + 8 + k, ph[k]);
+    if (lane == 0) {
+        for (int k = 0; k < 8; ++k) atomicAdd(P.stats + 8 + k, ph[k]);
+        for (int k = 8; k < 16; ++k) atomicAdd(P.stats + 80 + (k - 8), ph[k]);      // finer split: see tools/phase_shares.py
+    }
 #elif defined(RT_BLOCK_COUNTS)
     if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(P.stats + 8 + k, (unsigned long long)s_cnt[tid >> 6][k]);
 #endif

@@ -141,6 +141,21 @@ def model_grid_cells(o, d, g, G, scale, rng, shrink=0.25):
         bad = ~((fx0 <= fx1) & (fz0 <= fz1))
         cl = lambda v: np.clip(np.floor(np.nan_to_num(v, nan=0.0, posinf=1e9, neginf=-1e9)), 0, G - 1).astype(np.int64)
         ix0, ix1, iz0, iz1 = cl(fx0), cl(fx1), cl(fz0), cl(fz1)
+        # the footprint row by row (GridSeg / grid_row_run: grids of more than 64 cells): columns of every grid row
+        Xa, Xb = ((xa - g[0]) * g[2]).astype(f32), ((xb - g[0]) * g[2]).astype(f32)
+        Za, Zb = ((za - g[1]) * g[2]).astype(f32), ((zb - g[1]) * g[2]).astype(f32)
+        Xlo, Xhi, Zlo, Zhi = np.minimum(Xa, Xb), np.maximum(Xa, Xb), np.minimum(Za, Zb), np.maximum(Za, Zb)
+        SL = np.where(np.abs(Zb - Za) >= f32(1e-2), (Xb - Xa) * ulp_jitter((f32(1.0) / (Zb - Za).astype(np.float64)).astype(f32), rng), f32(np.nan)).astype(f32)
+        m = ((g[7] + f32(10.0) * e) * g[2] + f32(1e-3 * shrink)).astype(f32)
+        rows = np.arange(G, dtype=np.float32)[None, :]
+        zl = np.maximum(Zlo[:, None], rows - m[:, None]).astype(f32)
+        zh = np.minimum(Zhi[:, None], rows + f32(1.0) + m[:, None]).astype(f32)
+        xl = ((zl - Za[:, None]) * SL[:, None] + Xa[:, None]).astype(f32)
+        xh = ((zh - Za[:, None]) * SL[:, None] + Xa[:, None]).astype(f32)
+        whole = ~((np.abs(xl) < f32(1e30)) & (np.abs(xh) < f32(1e30)))
+        lo = np.where(whole, Xlo[:, None], np.maximum(np.minimum(xl, xh) - f32(1e-2 * shrink), Xlo[:, None])) - m[:, None]
+        hi = np.where(whole, Xhi[:, None], np.minimum(np.maximum(xl, xh) + f32(1e-2 * shrink), Xhi[:, None])) + m[:, None]
+        model_grid_cells.row_runs = (cl(lo.astype(f32)), cl(hi.astype(f32)))          # [rays, G] each; valid for rows iz0..iz1
     kind = np.where(~sane, -1, np.where(miss, 0, np.where(far | bad, -1, 1)))
     return ix0, ix1, iz0, iz1, kind
 
@@ -195,21 +210,35 @@ def test_a_sphere_the_reference_can_hit_lies_in_a_cell_of_the_rays_footprint(nam
     cell = cell_slots // 32 - n_global
     six, siz = cell % G, cell // G
     c, r = flat["center"][idx], np.abs(flat["radius"][idx])
-    n_rays, checked, rect_cells = 6000, 0, []
+    n_rays, checked, rect_cells, line_cells = 6000, 0, [], []
     for lo in range(0, n_rays, 500):
         o, d = rays_for(flat, g, rng, 500)
         ix0, ix1, iz0, iz1, kind = model_grid_cells(o, d, g, G, scale, rng)
         hits = reference_hits(o, d, c, r)
         inside = (six[None, :] >= ix0[:, None]) & (six[None, :] <= ix1[:, None]) & (siz[None, :] >= iz0[:, None]) & (siz[None, :] <= iz1[:, None])
+        n_cells = (ix1 - ix0 + 1) * (iz1 - iz0 + 1)
+        if n_global + G * G > 64:
+            # the kernel instantiation for large grids marks the cells row by row: the sphere's column must lie in the run
+            # of the sphere's row (and the rows are those of the rectangle)
+            rlo, rhi = model_grid_cells.row_runs
+            ray = np.arange(len(o))[:, None]
+            inside &= (six[None, :] >= rlo[ray, siz[None, :]]) & (six[None, :] <= rhi[ray, siz[None, :]])
+            rowsel = (np.arange(G)[None, :] >= iz0[:, None]) & (np.arange(G)[None, :] <= iz1[:, None])
+            n_row_cells = np.where(rowsel, rhi - rlo + 1, 0).sum(1)
+            assert np.all(n_row_cells[kind == 1] <= n_cells[kind == 1])         # never more than the rectangle
+            line_cells.append(np.where(kind == 1, n_row_cells, 0))
+            n_cells = n_row_cells
         ok = (kind[:, None] == -1) | ((kind[:, None] == 1) & inside)
         bad = hits & ~ok
         assert not bad.any(), (name, np.argwhere(bad)[:5], o[np.argwhere(bad)[0][0]], d[np.argwhere(bad)[0][0]])
         checked += int(hits.sum())
-        rect_cells.append(np.where(kind == 1, (ix1 - ix0 + 1) * (iz1 - iz0 + 1), 0))
+        rect_cells.append(np.where(kind == 1, n_cells, 0))
     assert checked > 2000                                    # the statement was tested on real hits
     # and the footprints are not trivially "everything": the typical ray marks a small part of the grid
     rc = np.concatenate(rect_cells)
     assert np.median(rc[rc > 0]) <= max(4, G * G // 4)
+    if line_cells:
+        print(name, "cells per footprint: mean", np.concatenate(line_cells)[rc > 0].mean())
 
 
 def test_the_model_can_fail():
