@@ -342,7 +342,7 @@ def main():
             #              MI355X_MICROARCH.md's constants); `peak_uniform` = 1024 x 2.4 / 2, every instruction at 2 cycles;
             #   frac     = achieved / peak;  `valu_busy` = the measured share of SIMD cycles in which a vector
             #              instruction is issuing (SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles)) -- a utilisation, not a roofline.
-            "bound": "valu-issue", "kernel": f"rt::render_kernel<{step.scan_mode}, false, {'true' if step.kernel_variant else 'false'}>",
+            "bound": "valu-issue", "kernel": f"rt::render_kernel<{step.scan_mode}, false, {'true' if step.kernel_variant & 1 else 'false'}>",
             "achieved": None, "peak": None, "unit": "G vector wave-instructions/s", "frac": None,
             "kernel_ms": round(k_ms, 3), "kernel_ms_source": "HIP events on the launch stream, this run",
             "launches_timed": len(kernel_ms),

@@ -31,6 +31,7 @@ pub const RT_DIALECTRIC: i32 = 2;
 pub const RT_FLAG_ACCUMULATE: u32 = 0x1;
 pub const RT_FLAG_NO_FILTER: u32 = 0x2;
 pub const RT_FLAG_DIAG_STATS: u32 = 0x4;
+pub const RT_FLAG_UNIFORM53: u32 = 0x8;
 
 /// Opaque `rt_context`.
 #[repr(C)]

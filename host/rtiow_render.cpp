@@ -4,7 +4,7 @@
 //
 //   rtiow_render [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--scene-seed S]
 //                [--grid LO HI] [--device K] [--out image.ppm] [--dump-scene scene.bin] [--scene scene.bin]
-//                [--devices 0,1,..  [--tile-rows T] [--force-rccl]]
+//                [--devices 0,1,..  [--tile-rows T] [--force-rccl]] [--uniform53]
 //
 // --devices: the frame's rows are dealt round-robin to one rt_context per listed device, each driven by
 // its own host thread, and gathered with ONE RCCL ncclGather to the first device (host/rtiow_multi.hpp).
@@ -31,7 +31,7 @@ int main(int argc, char **argv)
     unsigned long long seed = 1, scene_seed = 1;
     std::string out = "image.ppm", dump, scene_file;
     std::vector<int> devices;                    // --devices 0,1,...: one context + host thread per entry
-    bool force_rccl = false;
+    bool force_rccl = false, uniform53 = false;
     int tile_rows = 1;
     for (int i = 1; i < argc; ++i) {
         auto arg = [&](const char *n) { return !std::strcmp(argv[i], n) && i + 1 < argc; };
@@ -46,6 +46,7 @@ int main(int argc, char **argv)
         else if (arg("--devices")) { for (char *t = std::strtok(argv[++i], ","); t; t = std::strtok(nullptr, ",")) devices.push_back(std::atoi(t)); }
         else if (arg("--tile-rows")) tile_rows = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--force-rccl")) force_rccl = true;
+        else if (!std::strcmp(argv[i], "--uniform53")) uniform53 = true;
         else if (arg("--dump-scene")) dump = argv[++i];
         else if (arg("--scene")) scene_file = argv[++i];
         else if (!std::strcmp(argv[i], "--grid") && i + 2 < argc) { lo = std::atoi(argv[++i]); hi = std::atoi(argv[++i]); }
@@ -76,7 +77,7 @@ int main(int argc, char **argv)
                             (double)width / (double)height, 0.1, 10.0);             // main.rs:108-118
     rt_params p{};
     p.width = width; p.height = height; p.spp = spp; p.sample_begin = 0; p.max_depth = depth;
-    p.t_min = 0.0001; p.seed = seed; p.tile_rows = 8; p.shard_index = 0; p.shard_count = 1; p.flags = 0;
+    p.t_min = 0.0001; p.seed = seed; p.tile_rows = 8; p.shard_index = 0; p.shard_count = 1; p.flags = uniform53 ? RT_FLAG_UNIFORM53 : 0u;
     const size_t npix = (size_t)width * height;
     const rt_camera rc_cam = cam.flat();
     std::vector<uint8_t> rgba(npix * 4);

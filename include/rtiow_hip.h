@@ -109,6 +109,10 @@ typedef struct {
 #define RT_FLAG_ACCUMULATE 0x1u  /* rt_render_device: add to d_fix instead of overwriting it */
 #define RT_FLAG_NO_FILTER  0x2u  /* validation: send EVERY sphere to the exact f64 test     */
 #define RT_FLAG_DIAG_STATS 0x4u  /* also fill rt_stats.candidates / exact_roots / live_per_bounce (~15 % slower) */
+#define RT_FLAG_UNIFORM53  0x8u  /* every uniform from TWO Philox words, u = ((w0 << 32 | w1) >> 11) * 2^-53: the 53 random bits of
+                                    rand's gen::<f64>() (main.rs:131-132, vec3.rs:31-33,63, materials.rs:96) instead of 24; same draw
+                                    order; another (equally valid) random stream, so frames differ from the default's; scan mode 5 or
+                                    RT_FLAG_NO_FILTER, not with RT_FLAG_DIAG_STATS */
 
 typedef struct {
     uint64_t samples;            /* pixel-samples finished                          */
@@ -121,8 +125,9 @@ typedef struct {
     int32_t  grid_blocks, block_threads;
     int32_t  scan_mode;          /* sphere-scan filter that ran: 0 none (RT_FLAG_NO_FILTER), 5 tube filter (shipped),
                                     1 VALU cross-check (RTIOW_SCAN_MODE=1); 2-4 only in RTIOW_CROSSCHECK_MODES builds */
-    int32_t  kernel_variant;     /* which instantiation of the scan_mode-5 kernel ran: 1 the one for scenes whose tile
-                                    grid has <= 64 cells, 0 the general one (and every other scan mode) */
+    int32_t  kernel_variant;     /* which instantiation of the kernel ran, as bits: 1 the scan_mode-5 kernel for scenes whose
+                                    tile grid has <= 64 cells (else the general one, and every other scan mode); 2 the
+                                    RT_FLAG_UNIFORM53 instantiation */
     uint64_t live_per_bounce[64]; /* rays traced at bounce index k (0 = camera ray; indices >= 63 share the
                                     last slot); sums to rays_traced (RT_FLAG_DIAG_STATS, else 0) */
     uint64_t direct_samples;     /* samples added to the frame buffer one by one instead of through their block's

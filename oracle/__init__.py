@@ -28,7 +28,7 @@ class params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32),
                 ("sample_begin", C.c_int32), ("max_depth", C.c_int32),
                 ("row_begin", C.c_int32), ("row_end", C.c_int32), ("row_step", C.c_int32),
-                ("seed", C.c_uint64), ("t_min", C.c_double), ("nthreads", C.c_int32)]
+                ("seed", C.c_uint64), ("t_min", C.c_double), ("nthreads", C.c_int32), ("flags", C.c_uint32)]
 
 
 class stats(C.Structure):
@@ -70,6 +70,7 @@ def load():
     lib.oracle_scatter.argtypes = [C.POINTER(sphere), d3, d3, d3, C.c_int, d3, C.c_int, C.POINTER(C.c_int), d3, d3]
     lib.oracle_to_rgba.argtypes = [d3, C.c_int64, C.POINTER(C.c_uint8)]
     lib.oracle_get_ray.argtypes = [C.POINTER(camera), C.c_double, C.c_double, C.c_double, C.c_double, d3, d3]
+    lib.oracle_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p]
     lib.oracle_hardware_threads.restype = C.c_int
     _lib = lib
     return lib
@@ -98,13 +99,18 @@ def book1_camera(width, height):
     return camera_new((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, float(width) / float(height), 0.1, 10.0)
 
 
-def make_params(width, height, spp, *, sample_begin=0, max_depth=50, rows=None, seed=1, t_min=1e-4, nthreads=0):
-    """rows = (begin, end, step) over image rows j (0 = bottom); default all rows."""
+FLAG_UNIFORM53 = 0x8
+
+
+def make_params(width, height, spp, *, sample_begin=0, max_depth=50, rows=None, seed=1, t_min=1e-4, nthreads=0, uniform53=False):
+    """rows = (begin, end, step) over image rows j (0 = bottom); default all rows.
+    uniform53: two Philox words per uniform (53 random bits), the mirror of RT_FLAG_UNIFORM53."""
     p = params()
     p.width, p.height, p.spp, p.sample_begin, p.max_depth = width, height, spp, sample_begin, max_depth
     b, e, s = rows if rows is not None else (0, height, 1)
     p.row_begin, p.row_end, p.row_step = b, e, s
     p.seed, p.t_min, p.nthreads = seed, t_min, nthreads
+    p.flags = FLAG_UNIFORM53 if uniform53 else 0
     return p
 
 
@@ -178,3 +184,10 @@ def camera_from_host(cam):
         setattr(c, name, (C.c_double * 3)(float(a[0]), float(a[1]), float(a[2])))
     c.lens_radius = float(cam.lens_radius)
     return c
+
+
+def uniforms(seed, pixel, sample, count, uniform53=False):
+    """The first `count` uniforms of the stream of (pixel, sample), taken as one run."""
+    out = np.zeros(count, dtype=np.float64)
+    load().oracle_uniforms(seed, pixel, sample, FLAG_UNIFORM53 if uniform53 else 0, count, out.ctypes.data_as(C.c_void_p))
+    return out

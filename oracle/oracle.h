@@ -66,7 +66,12 @@ typedef struct {
     uint64_t seed;
     double t_min;           /* 1e-4 in the reference (main.rs:44)       */
     int32_t nthreads;       /* <=0: all hardware threads                */
+    uint32_t flags;         /* ORACLE_FLAG_*                            */
 } oracle_params;
+/* Every uniform from TWO consecutive Philox words, u = ((w0 << 32 | w1) >> 11) * 2^-53 (the 53 random bits of rand 0.8.5's
+ * gen::<f64>(), main.rs:131-132, vec3.rs:31-33,63, materials.rs:96) instead of one word's 24 bits; same draw order, same
+ * runs of consecutive words (oracle_common.h).  Mirrors RT_FLAG_UNIFORM53 of include/rtiow_hip.h. */
+#define ORACLE_FLAG_UNIFORM53 0x8u
 
 typedef struct {
     uint64_t samples;
@@ -124,6 +129,9 @@ void oracle_to_rgba(const double c[3], int64_t spp, uint8_t out[4]);
 /* one camera ray for given (s,t) and lens sample (camera.rs:47-54). */
 void oracle_get_ray(const oracle_camera *cam, double s, double t, double lens_x, double lens_y,
                     double orig[3], double dir[3]);
+
+/* first `count` uniforms of the stream of (pixel, sample) as one run (24-bit, or 53-bit with ORACLE_FLAG_UNIFORM53) */
+void oracle_uniforms(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t flags, int32_t count, double *out);
 
 int oracle_hardware_threads(void);
 

@@ -9,14 +9,13 @@
  *
  * Stream addressing:
  *   key     = (seed lo32, seed hi32)
- *   counter = (pixel index j*W+i, sample index, event index, 0)
- * One Philox4x32-10 block per "event":
- *   event 0 of a sample       -> words (0,1,2,3) = (u jitter, v jitter, lens x, lens y)
- *   every further lens retry  -> words (0,1)     = (lens x, lens y)
- *   unit-sphere rejection try -> words (0,1,2)   = (x, y, z)
- *   Dialectric reflectance    -> word  0
- * A 32-bit word w becomes the uniform u = (w >> 8) * 2^-24 in [0,1): exactly
- * representable in f32 and f64, so A and B consume identical numbers.
+ *   counter = (pixel index j*W+i, sample index, block index e, 0)
+ * The Philox4x32-10 blocks B_0, B_1, ... of one (pixel, sample) are consumed in RUNS of consecutive
+ * words (see oracle_rng below): the camera run, one run per Lambertian/Metal scatter, one per
+ * Dialectric reflectance draw.
+ * A 32-bit word w becomes the uniform u = (w >> 8) * 2^-24 in [0,1): exactly representable in f32
+ * and f64, so A and B consume identical numbers.  With ORACLE_FLAG_UNIFORM53 a uniform takes TWO
+ * consecutive words, u = ((w0 << 32 | w1) >> 11) * 2^-53.
  */
 #ifndef RTIOW_ORACLE_COMMON_H
 #define RTIOW_ORACLE_COMMON_H
@@ -58,6 +57,7 @@ typedef struct {
     uint32_t k0, k1, pixel, sample, event;
     uint32_t w[4];
     int have;               /* words of the current block not yet taken: w[4 - have .. 3] */
+    int u53;                /* ORACLE_FLAG_UNIFORM53: two words per uniform */
     const double *explicit_u;
     int explicit_n, explicit_used;
 } oracle_rng;
@@ -65,8 +65,18 @@ typedef struct {
 static inline void rng_init(oracle_rng *r, uint64_t seed, uint32_t pixel, uint32_t sample)
 {
     r->k0 = (uint32_t)seed; r->k1 = (uint32_t)(seed >> 32);
-    r->pixel = pixel; r->sample = sample; r->event = 0; r->have = 0;
+    r->pixel = pixel; r->sample = sample; r->event = 0; r->have = 0; r->u53 = 0;
     r->explicit_u = 0; r->explicit_n = 0; r->explicit_used = 0;
+}
+
+static inline uint32_t rng_word(oracle_rng *r)
+{
+    if (r->have == 0) {
+        philox4x32_10(r->pixel, r->sample, r->event, 0u, r->k0, r->k1, r->w);
+        r->event++;
+        r->have = 4;
+    }
+    return r->w[4 - r->have--];
 }
 
 /* Next `count` words of the current run as uniforms k * 2^-24 (exact in f64). */
@@ -80,13 +90,12 @@ static inline void rng_take(oracle_rng *r, int count, double *u)
         return;
     }
     for (int i = 0; i < count; ++i) {
-        if (r->have == 0) {
-            philox4x32_10(r->pixel, r->sample, r->event, 0u, r->k0, r->k1, r->w);
-            r->event++;
-            r->have = 4;
+        if (r->u53) {       /* 53 bits from two consecutive words (a pair never straddles a block: runs take even counts) */
+            const uint64_t hi = rng_word(r), lo = rng_word(r);
+            u[i] = (double)(((hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+        } else {
+            u[i] = (double)(rng_word(r) >> 8) * (1.0 / 16777216.0);
         }
-        u[i] = (double)(r->w[4 - r->have] >> 8) * (1.0 / 16777216.0);
-        r->have--;
     }
 }
 static inline void rng_end_run(oracle_rng *r) { r->have = 0; }

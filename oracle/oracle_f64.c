@@ -220,6 +220,7 @@ static ray get_ray(const oracle_camera *c, double s, double t, double lens_x, do
 static ray sample_ray(const oracle_camera *cam, const oracle_params *p, int i, int j, int s, oracle_rng *rng)
 {
     rng_init(rng, p->seed, (uint32_t)j * (uint32_t)p->width + (uint32_t)i, (uint32_t)s);
+    rng->u53 = (p->flags & ORACLE_FLAG_UNIFORM53) != 0;
     double e[4];
     rng_take(rng, 4, e);                                       /* B_0: one run with the lens tries that follow */
     double u = ((double)i + e[0]) / (double)(p->width - 1);    /* main.rs:131 */
@@ -531,4 +532,13 @@ void oracle_get_ray(const oracle_camera *cam, double s, double t, double lens_x,
     ray r = get_ray(cam, s, t, lens_x, lens_y);
     orig[0] = r.orig.x; orig[1] = r.orig.y; orig[2] = r.orig.z;
     dir[0] = r.dir.x; dir[1] = r.dir.y; dir[2] = r.dir.z;
+}
+
+/* The first `count` uniforms of the stream of (pixel, sample), taken as ONE run (unit tests of the word -> uniform rule). */
+void oracle_uniforms(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t flags, int32_t count, double *out)
+{
+    oracle_rng rng;
+    rng_init(&rng, seed, pixel, sample);
+    rng.u53 = (flags & ORACLE_FLAG_UNIFORM53) != 0;
+    rng_take(&rng, count, out);
 }

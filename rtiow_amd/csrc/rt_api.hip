@@ -298,13 +298,13 @@ int upload_table(T **dst, const T *src, size_t count)
     return RT_OK;
 }
 
-template <int MODE, bool DIAG, bool SMALLGRID = false>
+template <int MODE, bool DIAG, bool SMALLGRID = false, bool U53 = false>
 int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, int *grid_out)
 {
     int per_cu = ctx->blocks_per_cu;
     if (per_cu <= 0) {
         int occ = 0;
-        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rt::render_kernel<MODE, DIAG, SMALLGRID>, rt::kBlock, 0));
+        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rt::render_kernel<MODE, DIAG, SMALLGRID, U53>, rt::kBlock, 0));
         per_cu = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
     }
     // persistent grid, but never more lanes than there are work items
@@ -314,7 +314,7 @@ int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, in
     if (grid < 1) grid = 1;
     *grid_out = (int)grid;
     RT_HIP(hipEventRecord(ctx->ev0, stream));
-    hipLaunchKernelGGL((rt::render_kernel<MODE, DIAG, SMALLGRID>), dim3((unsigned)grid), dim3(rt::kBlock), 0, stream, kp);
+    hipLaunchKernelGGL((rt::render_kernel<MODE, DIAG, SMALLGRID, U53>), dim3((unsigned)grid), dim3(rt::kBlock), 0, stream, kp);
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(ctx->ev1, stream));
     return RT_OK;
@@ -783,6 +783,20 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     const int mode = (p->flags & RT_FLAG_NO_FILTER) ? 0 : ctx->scan_mode;
     ctx->last.scan_mode = mode;
     ctx->last.kernel_variant = 0;
+    const bool small_grid = ctx->grid_dim > 0 && ctx->n_global + ctx->grid_dim * ctx->grid_dim <= 64;
+    if (p->flags & RT_FLAG_UNIFORM53) {
+        // 53-bit uniforms: instantiated for the shipped scan mode (both grid variants) and for RT_FLAG_NO_FILTER
+        if (diag || (mode != 0 && mode != 5))
+            return fail(RT_ERR_INVALID_ARGUMENT, "RT_FLAG_UNIFORM53 runs with scan mode 5 (the default) or RT_FLAG_NO_FILTER, without RT_FLAG_DIAG_STATS");
+        if (mode == 0) rc = launch_render<0, false, false, true>(ctx, kp, stream, &grid);
+        else if (small_grid) rc = launch_render<5, false, true, true>(ctx, kp, stream, &grid);
+        else rc = launch_render<5, false, false, true>(ctx, kp, stream, &grid);
+        if (rc) return rc;
+        ctx->last.kernel_variant = 2 | ((mode == 5 && small_grid) ? 1 : 0);
+        ctx->launched = true;
+        ctx->last.grid_blocks = grid;
+        return RT_OK;
+    }
     switch (mode * 2 + (diag ? 1 : 0)) {
     case 0: rc = launch_render<0, false>(ctx, kp, stream, &grid); break;
     case 1: rc = launch_render<0, true>(ctx, kp, stream, &grid); break;
@@ -797,7 +811,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     case 9: rc = launch_render<4, true>(ctx, kp, stream, &grid); break;
 #endif
     case 10:        // (the shipped kernel has a leaner instantiation for scenes whose tile grid has <= 64 cells)
-        if (ctx->grid_dim > 0 && ctx->n_global + ctx->grid_dim * ctx->grid_dim <= 64) {
+        if (small_grid) {
             rc = launch_render<5, false, true>(ctx, kp, stream, &grid);
             ctx->last.kernel_variant = 1;
         } else rc = launch_render<5, false>(ctx, kp, stream, &grid);

@@ -88,6 +88,15 @@ __device__ __forceinline__ double u01(uint32_t w) { return (double)(w >> 8) * (1
 // gen_range(-1.0..1.0) / (-1.0..=1.0): 2u - 1 (exact).
 __device__ __forceinline__ double u11(uint32_t w) { return 2.0 * u01(w) - 1.0; }
 
+// RT_FLAG_UNIFORM53: a uniform from TWO consecutive words, u = ((w0 << 32 | w1) >> 11) * 2^-53 -- the 53 random bits of
+// rand 0.8.5's gen::<f64>() (main.rs:131-132, materials.rs:96).  k = w0 * 2^21 + (w1 >> 11) < 2^53: both conversions, the
+// sum and the scaling are exact.  Ranges (-1..1) and (-1..=1) map to 2u - 1 (exact: an even integer of at most 54 bits / 2^53).
+__device__ __forceinline__ double u01_53(uint32_t w0, uint32_t w1)
+{
+    return ((double)w0 * 2097152.0 + (double)(w1 >> 11)) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ double u11_53(uint32_t w0, uint32_t w1) { return 2.0 * u01_53(w0, w1) - 1.0; }
+
 // The reference's rejection tests on such uniforms (vec3.rs:37-45 `length_squared() < 1.0`, vec3.rs:59-68), exactly.
 // u11(w) = m * 2^-23 with the integer m = (w >> 8) - 2^23 in [-2^23, 2^23); m*m needs 46 bits and a sum of three
 // such squares 48, so every f64 product and sum in `x*x + y*y + z*z` is EXACT and the f64 comparison with 1.0 is

@@ -142,7 +142,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ~15 % of the frame time.
 // SMALLGRID (MODE 5 only): the scene's tile grid has at most 64 cells (with the global tiles: a list of <= 64 tiles) --
 // the host picks this instantiation then; it carries neither the large-grid list code nor the scan-every-tile fallback.
-template <int MODE, bool DIAG, bool SMALLGRID = false>
+// U53 (RT_FLAG_UNIFORM53): every uniform takes two consecutive Philox words (53 random bits, as rand's gen::<f64>()) instead
+// of one word's 24 bits: same draw order, same runs; the rejection tests run in f64 as the reference writes them (the
+// integer form needs the 2^-23 lattice).  An optional mode: ~2x the Philox work of the retry loops.
+template <int MODE, bool DIAG, bool SMALLGRID = false, bool U53 = false>
 // second launch bound = waves per SIMD the register allocator must leave room for: the bounce loop
 // is latency-bound, and the 4th wave is worth more than the few cold values it spills.  Only the shipped kernel
 // (MODE 5 without the diagnostic counters) fits four workgroups' LDS on a CU (40 000 of 40 960 bytes each); the
@@ -343,13 +346,23 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     const uint32_t g_s = (uint32_t)P.sample_begin + (s_rel - dq * (uint32_t)P.spp);
                     U4 w = philox4x32_10(g_pix, g_s, 0u, 0u, P.k0, P.k1);
                     uint32_t g_ev = 1u;
-                    const double u = ((double)i + u01(w.x)) / wm1;                   // main.rs:131
-                    const double v = ((double)j + u01(w.y)) / hm1;                   // main.rs:132
+                    const double u = ((double)i + (U53 ? u01_53(w.x, w.y) : u01(w.x))) / wm1;     // main.rs:131
+                    const double v = ((double)j + (U53 ? u01_53(w.z, w.w) : u01(w.y))) / hm1;     // main.rs:132
                     // vec3.rs:59-68: redraw until x*x + y*y < 1.  x = u11(w) = m * 2^-23 with the integer m = (w >> 8) - 2^23, and
                     // the f64 sum of squares of such values is EXACT (47 bits), so the reference's f64 comparison is the integer
                     // comparison m_x^2 + m_y^2 < 2^46: the loop runs on integers, the accepted pair is converted once.
                     // Block 0 = (u jitter, v jitter, lens x, lens y); every further block holds TWO tries.
                     uint32_t wx = w.z, wy = w.w;
+                    if constexpr (U53) {
+                        // B_0 = (u jitter, v jitter), then ONE block per unit-disk try (two 53-bit draws); vec3.rs:59-68 in f64 as
+                        // written.  The queue keeps no lens words: the lane that takes the sample recomputes block g_ev - 1.
+                        double lx, ly;
+                        do {
+                            w = philox4x32_10(g_pix, g_s, g_ev, 0u, P.k0, P.k1);
+                            g_ev++;
+                            lx = u11_53(w.x, w.y); ly = u11_53(w.z, w.w);
+                        } while (!(lx * lx + ly * ly < 1.0));
+                    } else
                     while (!unit_disk_accepts(wx, wy)) {
                         w = philox4x32_10(g_pix, g_s, g_ev, 0u, P.k0, P.k1);
                         g_ev++;
@@ -388,7 +401,11 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
         }
         RT_STAMP(0);
         if (fresh) {                                                // camera.rs:47-54
-            const double lx = u11(lens_wx), ly = u11(lens_wy);
+            double lx = u11(lens_wx), ly = u11(lens_wy);
+            if constexpr (U53) {                                    // the accepted unit-disk try is the last block the start drew
+                const U4 lb = philox4x32_10(pix_global, (uint32_t)s, ev - 1u, 0u, P.k0, P.k1);
+                lx = u11_53(lb.x, lb.y); ly = u11_53(lb.z, lb.w);
+            }
             const D3 cam_origin = ld3(P.cam.origin);
             const D3 rd = mk(lx, ly, 0.0) * P.cam.lens_radius;
             const D3 offset = ld3(P.cam.u) * rd.x + ld3(P.cam.v) * rd.y;
@@ -1094,7 +1111,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             bool front = false;
             D3 p = o, nrm = mk(0.0, 0.0, 0.0), sp = mk(0.0, 0.0, 0.0), albedo = mk(1.0, 1.0, 1.0);
             double param = 0.0, inv_param = 0.0, r0_front = 0.0, r0_back = 0.0;
-            uint32_t w_first = 0u;
+            uint32_t w_first = 0u, w_second = 0u;
             if (is_hit) {
                 const double *mrec = mat + kMatStride * (size_t)hit;
                 const double4 g = *reinterpret_cast<const double4 *>(geo + 4 * (size_t)hit);
@@ -1114,7 +1131,39 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 // really made -- the Dialectric's reflectance draw.  One wave-level call, not two.
                 U4 w = philox4x32_10(pix_global, (uint32_t)s, ev, 0u, P.k0, P.k1);
                 w_first = w.x;
+                if constexpr (U53) w_second = w.y;
                 RT_STAMP(11);
+                if constexpr (U53) {
+                  if (kind != RT_KIND_DIALECTRIC) {
+                    // vec3.rs:37-45 with 53-bit draws: a try is SIX consecutive words -- two tries per three blocks -- and the
+                    // test is the reference's own f64 expression x*x + y*y + z*z < 1.0 (vec3.rs:87-89)
+                    U4 b1 = philox4x32_10(pix_global, (uint32_t)s, ev + 1u, 0u, P.k0, P.k1);
+                    uint32_t nblk = 2u, c0 = b1.z, c1 = b1.w;
+                    double sx = u11_53(w.x, w.y), sy = u11_53(w.z, w.w), sz = u11_53(b1.x, b1.y);
+                    bool ok = sx * sx + sy * sy + sz * sz < 1.0;
+                    while (!ok) {
+                        RT_COUNT(6);
+                        U4 b = philox4x32_10(pix_global, (uint32_t)s, ev + nblk, 0u, P.k0, P.k1);
+                        nblk++;
+                        sx = u11_53(c0, c1); sy = u11_53(b.x, b.y); sz = u11_53(b.z, b.w);       // try 2m+1: ends its block
+                        ok = sx * sx + sy * sy + sz * sz < 1.0;
+                        if (!ok) {
+                            b = philox4x32_10(pix_global, (uint32_t)s, ev + nblk, 0u, P.k0, P.k1);
+                            b1 = philox4x32_10(pix_global, (uint32_t)s, ev + nblk + 1u, 0u, P.k0, P.k1);
+                            nblk += 2u;
+                            sx = u11_53(b.x, b.y); sy = u11_53(b.z, b.w); sz = u11_53(b1.x, b1.y); // try 2m+2 = try 0 of the next three blocks
+                            c0 = b1.z; c1 = b1.w;
+                            ok = sx * sx + sy * sy + sz * sz < 1.0;
+                        }
+                    }
+                    ev += nblk;
+                    sp = mk(sx, sy, sz);
+                  } else {
+                    const double2 mD = *reinterpret_cast<const double2 *>(mrec + 6);  // 1/ir, r0(1/ir)
+                    const double2 mE = *reinterpret_cast<const double2 *>(mrec + 8);  // r0(ir), -
+                    inv_param = mD.x; r0_front = mD.y; r0_back = mE.x;
+                  }
+                } else
                 if (kind != RT_KIND_DIALECTRIC) {
                     // vec3.rs:37-45: redraw until |p|^2 < 1 -- on the integers behind the three uniforms, where the
                     // reference's f64 comparison is exact (see unit_sphere_accepts); converted once, after the loop.
@@ -1194,7 +1243,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                         const double x2 = x * x;
                         const double refl = r0 + (1.0 - r0) * ((x2 * x2) * x);   // materials.rs:80
                         ev++;                                                    // the block drawn above
-                        do_refract = refl <= u01(w_first);
+                        do_refract = refl <= (U53 ? u01_53(w_first, w_second) : u01(w_first));
                     }
                     ndir = do_refract ? refract(uV, nrm, ratio) : reflect(uV, nrm);
                 }
