@@ -315,13 +315,18 @@ def main():
         # from the committed passes of the same command (profiles/pmc_replay.json, written by
         # tools/summarize_profile.py) and only when the kernel sources are the profiled ones.
         sha = kernel_source_sha()
+        from rtiow_amd import _ffi
+        lib_sha = _ffi.load().rt_build_source_sha().decode()
         pmc, pmc_note = None, "no profiles/pmc_replay.json entry for this configuration"
         path = os.path.join(ROOT, "profiles", "pmc_replay.json")
         if os.path.exists(path):
             try:
                 for entry in json.load(open(path)).get("entries", []):
                     if entry.get("config") == [W, H, spp_frame, world]:
-                        if entry.get("kernel_source_sha") == sha:
+                        if lib_sha != sha:
+                            pmc_note = (f"the loaded library was built from kernel sources {lib_sha}, the tree is {sha}: "
+                                        f"rebuild (./build_lib.sh); no counters replayed")
+                        elif entry.get("kernel_source_sha") == sha:
                             pmc, pmc_note = entry, entry.get("source")
                         else:
                             pmc_note = (f"stale: {entry.get('source')} was taken on kernel sources "
@@ -425,7 +430,7 @@ def main():
                             + (" (REHEARSAL: all ranks on cuda:0, gloo gather)" if rehearse else ""),
                 "rays_per_sample": round(rays / max(1, samples), 4),
                 "frame_crc32": frame_crc,      # of the exact sums: equal for equal (W, H, spp) at any N
-                "kernel_source_sha": sha,
+                "kernel_source_sha": sha, "library_source_sha": lib_sha,
             },
             "roofline": roof,
         }

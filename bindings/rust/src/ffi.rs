@@ -131,6 +131,7 @@ extern "C" {
     pub fn rt_last_error() -> *const c_char;
     pub fn rt_backend_name() -> *const c_char;
     pub fn rt_abi_version() -> i32;
+    pub fn rt_build_source_sha() -> *const c_char;
     pub fn rt_f64_div_sqrt_device(ctx: *mut rt_context, a: *const f64, b: *const f64, n: i32,
                                   out_div: *mut f64, out_sqrt: *mut f64) -> i32;
     pub fn rt_quantize_device(ctx: *mut rt_context, x: *const f64, n: i32, out: *mut u64) -> i32;

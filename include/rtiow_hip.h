@@ -187,6 +187,9 @@ int rt_resolve_rgba8(rt_context *ctx, const uint64_t *fix, int32_t width, int32_
 const char *rt_last_error(void);
 const char *rt_backend_name(void);     /* "hip-gfx950" */
 int32_t rt_abi_version(void);
+/* sha256 (first 16 hex digits) over the three kernel sources this library was BUILT from, as the build recorded it
+ * ("unknown" for a build that did not pass it): bench.py labels its line with it, so that a stale .so shows */
+const char *rt_build_source_sha(void);
 /* Known-answer test hooks, computed ON THE DEVICE:
  * one Philox4x32-10 block; and elementwise a[i]/b[i] and sqrt(a[i]) in f64 (the
  * two operations whose correct rounding the bit-exact contract leans on). */

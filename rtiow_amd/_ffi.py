@@ -60,6 +60,7 @@ SYMBOLS = [
     ("rt_last_error", C.c_char_p, []),
     ("rt_backend_name", C.c_char_p, []),
     ("rt_abi_version", C.c_int32, []),
+    ("rt_build_source_sha", C.c_char_p, []),
     ("rt_philox_device", C.c_int, [_VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("rt_f64_div_sqrt_device", C.c_int, [_VP, _VP, _VP, C.c_int32, _VP, _VP]),
     ("rt_quantize_device", C.c_int, [_VP, _VP, C.c_int32, _VP]),

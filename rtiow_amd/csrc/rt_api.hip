@@ -463,6 +463,10 @@ extern "C" {
 const char *rt_last_error(void) { return g_err; }
 const char *rt_backend_name(void) { return "hip-gfx950"; }
 int32_t rt_abi_version(void) { return RTIOW_HIP_ABI_VERSION; }
+#ifndef RT_SOURCE_SHA
+#define RT_SOURCE_SHA "unknown"
+#endif
+const char *rt_build_source_sha(void) { return RT_SOURCE_SHA; }
 
 int rt_create(int32_t device_id, rt_context **out)
 {

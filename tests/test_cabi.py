@@ -56,6 +56,9 @@ def test_identity():
     lib = _ffi.load()
     assert lib.rt_backend_name() == b"hip-gfx950"
     assert lib.rt_abi_version() == 4
+    # the library on disk was built from the kernel sources of this tree (a stale .so would carry another sha)
+    import bench
+    assert lib.rt_build_source_sha().decode() == bench.kernel_source_sha(), "stale rtiow_amd/librtiow_hip.so: run ./build_lib.sh"
 
 
 @pytest.mark.parametrize("kw,msg", [

@@ -1,5 +1,7 @@
 """Randomised GPU-vs-oracle parity soak (development tool): many random scenes, cameras, image
-sizes and seeds; every frame must equal Oracle B bit for bit.  Usage: fuzz_parity.py [cases] [seed0]"""
+sizes and seeds; every frame must equal Oracle B bit for bit.  Usage: fuzz_parity.py [cases] [seed0]
+FUZZ_LARGE=p: share of scenes with enough spheres for a grid of more than 64 cells (default 0.15);
+FUZZ_U53=p: share of cases rendered with RT_FLAG_UNIFORM53 (default 0)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,7 +17,7 @@ tot_rays = 0
 for case in range(cases):
     rng = np.random.default_rng(seed0 * 100003 + case)
     n = int(rng.integers(1, 1200))
-    if rng.random() < 0.15:         # enough spheres for a grid of more than 64 cells (the kernel's second way of listing tiles)
+    if rng.random() < float(os.environ.get("FUZZ_LARGE", "0.15")):         # enough spheres for a grid of more than 64 cells (the kernel's second way of listing tiles)
         n = int(rng.integers(1200, 5000))
     spread = float(10.0 ** rng.uniform(0.0, 3.0))
     w = rt.HittableList()
@@ -43,13 +45,16 @@ for case in range(cases):
     cam = rt.Camera(lf, la, rt.Vec3(0, 1, 0), float(rng.uniform(5, 120)), W / H, float(rng.uniform(0.0, 0.5)) * spread / 10,
                     float(np.linalg.norm(lf - la)) + 1e-3)
     seed = int(rng.integers(1, 2 ** 62))
+    u53 = rng.random() < float(os.environ.get("FUZZ_U53", "0"))
     r.upload_scene(flat)
-    sm, fix, st = r.render(cam, rt.make_params(W, H, spp, seed=seed, tile_rows=int(rng.integers(1, 9))))
-    fb, sb, stb = oracle.render_b(oracle.camera_from_host(cam), flat, oracle.make_params(W, H, spp, seed=seed))
+    sm, fix, st = r.render(cam, rt.make_params(W, H, spp, seed=seed, tile_rows=int(rng.integers(1, 9)), flags=rt.RT_FLAG_UNIFORM53 if u53 else 0))
+    fb, sb, stb = oracle.render_b(oracle.camera_from_host(cam), flat, oracle.make_params(W, H, spp, seed=seed, uniform53=u53))
     ok = np.array_equal(fix, fb) and st["rays_traced"] == stb["rays_traced"]
     tot_rays += st["rays_traced"]
     if not ok:
         bad += 1
-        print(f"MISMATCH case {case}: n={len(flat)} {W}x{H}x{spp} spread={spread:.2f} diff px={int(np.count_nonzero((fix != fb).any(2)))}", flush=True)
+        print(f"MISMATCH case {case}: n={len(flat)} {W}x{H}x{spp} spread={spread:.2f} u53={u53} diff px={int(np.count_nonzero((fix != fb).any(2)))}", flush=True)
+    if (case + 1) % 1000 == 0:
+        print(f"   ... {case + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
 print(f"{cases} cases, {bad} mismatches, {tot_rays} rays, mode {os.environ.get('RTIOW_SCAN_MODE', '5 (default)')}, {time.time() - t0:.1f} s", flush=True)
 sys.exit(1 if bad else 0)
