@@ -27,7 +27,7 @@ use crate::shapes::{Hit, HittableList};
 pub struct MaterialDesc {
     pub kind: i32,          // RT_LAMBERTIAN / RT_METAL / RT_DIALECTRIC
     pub albedo: [f64; 3],   // Lambertian, Metal; (1,1,1) for Dialectric (its attenuation, materials.rs:103)
-    pub param: f64,         // Metal: fuzz (already clamped by Metal::new); Dialectric: ir
+    pub param: f64,         // Metal: fuzz AS STORED (Metal::new, materials.rs:39-46, does not clamp it); Dialectric: ir
 }
 
 // ---- the impls that go INTO the reference's modules (they read private fields) -----------------------------
