@@ -176,3 +176,29 @@ def test_get_ray_pinhole_centre(oracle_mod):        # camera.rs:47-54
     assert list(o) == [0, 0, 0] and np.allclose(list(d), [0, 0, -1], atol=1e-15)
     lib.oracle_get_ray(C.byref(cam), 0.0, 0.0, 0.0, 0.0, o, d)
     assert np.allclose(list(d), [-1, -1, -1], atol=1e-15)        # lower-left corner at 90 degrees
+
+
+def test_nan_and_infinite_roots_are_accepted_as_the_reference_accepts_them(oracle_mod):
+    """sphere.rs:29-33 rejects with `root < t_min || t_max < root`: false for a NaN root, so a zero-length direction
+    (a = 0, half_b = 0, disc = 0: root = 0/0) HITS every sphere; mod.rs:61-67 then carries closest_so_far = NaN, with which
+    `t_max < root` is false too: every later sphere with a root >= t_min (or NaN) is accepted and the LAST one wins,
+    whatever its distance.  An underflowing direction (a = 0, half_b != 0) gives roots of +-inf: +inf is accepted."""
+    lib = oracle_mod.load()
+    ok, t, p, n, front = hit(lib, (0, 0, -5), 1.0, (0, 0, 0), (0, 0, 0))
+    assert ok and math.isnan(t) and all(math.isnan(v) for v in p)
+    far, near = make_sphere(oracle_mod, (0, 0, -50), 1.0), make_sphere(oracle_mod, (0, 0, -5), 1.0)
+    for order, want in (((near, far), 1), ((far, near), 1)):                   # zero direction: the last of the list, always
+        arr = (oracle_mod.sphere * 2)(*order)
+        t = C.c_double()
+        assert lib.oracle_world_hit(arr, 2, d3(0, 0, 0), d3(0, 0, 0), 1e-4, C.byref(t)) == want and math.isnan(t.value)
+    # (an ordinary ray through the same list is unaffected: the nearest root >= t_min wins)
+    three = (oracle_mod.sphere * 3)(near, make_sphere(oracle_mod, (0, 0, 0), 1e-3), far)
+    t = C.c_double()
+    assert lib.oracle_world_hit(three, 3, d3(0, 0, 0), d3(0, 0, -1), 1e-4, C.byref(t)) == 1 and abs(t.value - 1e-3) < 1e-12
+    assert lib.oracle_world_hit(three, 3, d3(0, 0, 0), d3(0, 0, 0), 1e-4, C.byref(t)) == 2 and math.isnan(t.value)
+    # an underflowing direction: |d|^2 = 0 but d != 0; half_b^2 underflows too, disc = 0, root = -half_b / 0 = +inf
+    tiny = 1e-170
+    ok, t, p, n, front = hit(lib, (0, 0, -5), 1.0, (0, 0, 0), (0, 0, -tiny))
+    assert ok and t == math.inf
+    ok, t, p, n, front = hit(lib, (0, 0, 5), 1.0, (0, 0, 0), (0, 0, -tiny))   # moving away: -inf, then the far root -inf: a miss
+    assert not ok
