@@ -188,6 +188,9 @@ def main():
                     help="N=1 only: the single-GPU half of SURVEY.md 8(e)'s weak-scaling pair -- BASELINE configs[2], "
                          "3840x2160x500 = 4.147 G samples, the per-GPU share of the N>1 runs -- as a whole step "
                          "(render + gather + resolve), so that T(configs[2]) / T(N>1) can be formed from two `value`s")
+    ap.add_argument("--tenk", action="store_true",
+                    help="N=1 only: BASELINE configs[3] as the timed workload (10k random spheres, 1920x1080, 256 spp) -- "
+                         "what tools/profile_bench.sh profiles the large-grid kernel on")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 logic check on a 1-GPU box: every rank renders on cuda:0 and the gather runs "
                          "over gloo on CPU tensors (RCCL refuses two ranks on one device); not a measurement")
@@ -222,12 +225,17 @@ def main():
             sys.exit("--weak-baseline is the N = 1 comparator of the N > 1 runs")
         default_whs = (3840, 2160, 500)
         args.no_other_configs = args.no_cpu_baseline = True
+    if args.tenk:
+        if world != 1 or args.weak_baseline:
+            sys.exit("--tenk is a single-GPU workload")
+        default_whs = (1920, 1080, 256)
+        args.no_other_configs = True
     W = args.width or default_whs[0]
     H = args.height or default_whs[1]
     spp_share = args.spp or default_whs[2]
     spp_frame = spp_share * world                      # weak scaling: per-GPU samples fixed
     is_default = (W, H, spp_share) == default_whs
-    flat = rt.random_scene(1).flatten()
+    flat = (rt.random_scene(1, grid=(-50, 49)) if args.tenk else rt.random_scene(1)).flatten()
     cam = rt.book1_camera(W, H)
     renderer = rt.Renderer(local_rank)
     renderer.upload_scene(flat)
@@ -408,6 +416,20 @@ def main():
                 t = pmc["mfma_insts_per_launch"] * 32768 / (k_ms * 1e-3) / 1e12     # v_mfma_f32_32x32x16_bf16 = 32768 flop
                 roof["mfma"] = {"achieved_TFLOPs": round(t, 1), "peak_TFLOPs": PEAK_BF16_MFMA_TFLOPS,
                                 "frac": round(t / PEAK_BF16_MFMA_TFLOPS, 4)}
+        scene = (f"10k random spheres (random_scene seed 1 over a, b in -50..49, {n_sph} spheres)" if args.tenk else
+                 f"book-1 final scene (random_scene seed 1, {n_sph} spheres)")
+        if not is_default:
+            tag = "[custom size]"
+        elif args.tenk:
+            tag = "[BASELINE.json configs[3]]"
+        elif args.weak_baseline:
+            tag = "[BASELINE.json configs[2]: the N = 1 half of the weak-scaling pair, 4.147 G samples on one GPU]"
+        elif world == 1:
+            tag = "[the north_star target configuration: BASELINE.json configs[1]'s frame at 500 spp]"
+        else:
+            tag = (f"[BASELINE.json configs[4]'s geometry, 125 spp per GPU: {world}/8 of configs[4]; "
+                   f"4.147 G samples per GPU = configs[2] on one GPU]")
+        workload = f"{scene}, {W}x{H}, {spp_frame} spp, depth 50 {tag}"
         out = {
             "metric": baseline_metric(),
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world,
@@ -416,13 +438,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"book-1 final scene (random_scene seed 1, {n_sph} spheres), {W}x{H}, {spp_frame} spp, depth 50 "
-                            + (("[BASELINE.json configs[2]: the N = 1 half of the weak-scaling pair, 4.147 G samples on one GPU]"
-                                if args.weak_baseline else
-                                "[the north_star target configuration: BASELINE.json configs[1]'s frame at 500 spp]"
-                                if world == 1 else
-                                f"[BASELINE.json configs[4]'s geometry, 125 spp per GPU: {world}/8 of configs[4]; "
-                                f"4.147 G samples per GPU = configs[2] on one GPU]") if is_default else "[custom size]"),
+                "workload": workload,
                 "width": W, "height": H, "spp": spp_frame, "max_depth": 50, "n_spheres": n_sph,
                 "samples_per_gpu": frame_samples // world,
                 "sharding": "whole frame on one GPU" if world == 1 else
@@ -454,7 +470,8 @@ def main():
         out["gather_ms"] = round(float(np.mean(gather_ms)), 3)       # rank 0, mean per timed step (at N = 1: the copy into frame order)
         out["rmse_vs_cpu"] = None
         if world == 1 and not args.no_cpu_baseline:
-            cb, rows_j, cpu_sums = cpu_baseline(flat, W, H, spp_frame)
+            # (the 10k-sphere scene is ~20x slower per sample on the CPU: fewer rows there)
+            cb, rows_j, cpu_sums = cpu_baseline(flat, W, H, spp_frame, min_rows=6 if args.tenk else 100)
             out["cpu_baseline"] = cb
             out["cpu_baseline"]["gpu_over_cpu"] = round(value / cb["value"], 1)
             # the RMSE half of the metric, in the same run: the rows Oracle A has just rendered against the same rows of

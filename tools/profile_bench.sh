@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profiles `bench.py` on the GPU box: kernel trace + stats, then PMC passes (each in its own run, no trace
-# domains mixed with --pmc).  Two configurations: the bench default (1200x675x500, tag "target") and
-# BASELINE configs[1] (1200x675x100, tag "cfg2").  Output under gpurun_out/prof_<tag>/; summaries are copied
+# domains mixed with --pmc).  Three configurations: the bench default (1200x675x500, tag "target"),
+# BASELINE configs[1] (1200x675x100, tag "cfg2") and configs[3] (10k spheres, 1920x1080x256, tag "tenk": the large-grid kernel).  Output under gpurun_out/prof_<tag>/; summaries are copied
 # into profiles/ by tools/summarize_profile.py.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -27,3 +27,4 @@ run_cfg() {
 }
 run_cfg target
 run_cfg cfg2 --width 1200 --height 675 --spp 100
+run_cfg tenk --tenk

@@ -9,7 +9,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 import bench  # noqa: E402  (kernel_source_sha)
 
-CONFIGS = {"target": [1200, 675, 500, 1], "cfg2": [1200, 675, 100, 1]}
+CONFIGS = {"target": [1200, 675, 500, 1], "cfg2": [1200, 675, 100, 1], "tenk": [1920, 1080, 256, 1]}
 entries = []
 for cfg, shape in CONFIGS.items():
     prof = os.path.join(root, "gpurun_out", f"prof_{cfg}")
