@@ -223,3 +223,50 @@ def test_bench_two_ranks_rehearsed_on_one_gpu_give_the_single_gpu_frame():
     assert two["config"]["frame_crc32"] == one["config"]["frame_crc32"] is not None
     assert len(two["per_rank"]["kernel_ms"]) == 2 and all(v > 0 for v in two["per_rank"]["kernel_ms"])
     assert two["scaling"] == "weak" and two["value"] > 0 and one["rmse_vs_cpu"] is None
+
+
+# ---- material / geometry corners the reference allows and no other GPU test reaches ------------------------------------------
+
+def _hand(spheres):
+    w = rt.HittableList()
+    for s in spheres:
+        w.push(s)
+    return w.flatten()
+
+
+@pytest.mark.parametrize("case", ["inside_lambertian", "inside_metal_shell", "fuzz_above_one", "ir_below_and_at_one", "nested_glass"])
+def test_reference_corners_on_hand_scenes(renderer, oracle_mod, case):
+    """* the camera INSIDE a Lambertian / a Metal sphere: every hit is a back-face hit (mod.rs:21-22 flips the normal), the
+         scattered ray leaves the surface inwards and meets its own sphere again from inside (the far root, sphere.rs:30);
+       * Metal::new does not clamp fuzz (materials.rs:39-46): fuzz 3 throws most reflections below the surface (absorbed,
+         materials.rs:57-61);
+       * Dialectric with ir 0.5 (total internal reflection from OUTSIDE, refraction_ratio = 2) and ir 1.0 (no bending,
+         Schlick r0 = 0);
+       * a glass sphere inside a glass sphere inside a glass sphere (front / back faces alternate, long paths)."""
+    ground = rt.Sphere(rt.Point3(0, -1000, 0), 1000, rt.Lambertian(rt.Color(0.5, 0.5, 0.5)))
+    if case == "inside_lambertian":       # book camera at (13, 2, 3): enclosed by a sphere of radius 6 around it
+        flat = _hand([ground, rt.Sphere(rt.Point3(13, 2, 3), 6.0, rt.Lambertian(rt.Color(0.8, 0.7, 0.6))),
+                      rt.Sphere(rt.Point3(10, 1, 2), 1.0, rt.Metal(rt.Color(0.9, 0.9, 0.9), 0.1))])
+    elif case == "inside_metal_shell":
+        flat = _hand([rt.Sphere(rt.Point3(13, 2, 3), 8.0, rt.Metal(rt.Color(0.9, 0.8, 0.7), 0.05)),
+                      rt.Sphere(rt.Point3(9, 1, 2), 1.0, rt.Lambertian(rt.Color(0.2, 0.6, 0.9))),
+                      rt.Sphere(rt.Point3(11, 3, 5), 0.7, rt.Dialectric(1.5))])
+    elif case == "fuzz_above_one":
+        flat = _hand([ground] + [rt.Sphere(rt.Point3(2.2 * k, 1, 0), 1.0, rt.Metal(rt.Color(0.8, 0.8, 0.8), f))
+                                 for k, f in zip(range(-2, 3), (0.0, 1.0, 3.0, 10.0, 1.5))])
+    elif case == "ir_below_and_at_one":
+        flat = _hand([ground, rt.Sphere(rt.Point3(-2.5, 1, 0), 1.0, rt.Dialectric(0.5)), rt.Sphere(rt.Point3(0, 1, 0), 1.0, rt.Dialectric(1.0)),
+                      rt.Sphere(rt.Point3(2.5, 1, 0), 1.0, rt.Dialectric(1.0 / 1.5)), rt.Sphere(rt.Point3(5, 1, 0), 1.0, rt.Dialectric(4.0))])
+    else:
+        flat = _hand([ground, rt.Sphere(rt.Point3(0, 1.5, 0), 1.5, rt.Dialectric(1.5)), rt.Sphere(rt.Point3(0, 1.5, 0), 1.0, rt.Dialectric(1.3)),
+                      rt.Sphere(rt.Point3(0, 1.5, 0), 0.5, rt.Dialectric(2.0)), rt.Sphere(rt.Point3(0, 1.5, 0), -0.45, rt.Dialectric(2.0))])
+    w, h, spp = 96, 54, 40
+    cam = rt.book1_camera(w, h)
+    renderer.upload_scene(flat)
+    _, fix, st = renderer.render(cam, rt.make_params(w, h, spp))
+    fb, _, stb = oracle_mod.render_b(oracle_mod.camera_from_host(cam), flat, oracle_mod.make_params(w, h, spp))
+    assert np.array_equal(fix, fb) and st["rays_traced"] == stb["rays_traced"]
+    if case.startswith("inside"):
+        assert st["rays_traced"] > 3 * st["samples"]               # nothing escapes to the sky on the first ray
+    sa, sta = oracle_mod.render_a(oracle_mod.camera_from_host(cam), flat, oracle_mod.make_params(w, h, spp))
+    assert sta["rays_traced"] == st["rays_traced"]                  # and the literal (recursive) oracle walks the same paths
