@@ -270,3 +270,22 @@ def test_reference_corners_on_hand_scenes(renderer, oracle_mod, case):
         assert st["rays_traced"] > 3 * st["samples"]               # nothing escapes to the sky on the first ray
     sa, sta = oracle_mod.render_a(oracle_mod.camera_from_host(cam), flat, oracle_mod.make_params(w, h, spp))
     assert sta["rays_traced"] == st["rays_traced"]                  # and the literal (recursive) oracle walks the same paths
+
+
+def test_resume_from_a_checkpoint_equals_one_oracle_render(tmp_path, renderer, oracle_mod, book1_flat):
+    """SURVEY 8(f3), the whole flow: render 30 samples, save the exact sums (rtiow_amd.save_checkpoint), load them in a
+    'later session', render samples 30..99 and add: the frame equals ONE Oracle-B render of 100 samples (main.rs:130-137 is
+    the loop the two sessions split), and so do the RGBA8 bytes."""
+    w, h, seed = 150, 84, 0x5EED5EED5EED
+    cam = rt.book1_camera(w, h)
+    renderer.upload_scene(book1_flat)
+    _, first, _ = renderer.render(cam, rt.make_params(w, h, 30, seed=seed))
+    path = str(tmp_path / "frame.ckpt.npz")
+    rt.save_checkpoint(path, first, 30, seed)
+    fix, done, seed2 = rt.load_checkpoint(path)
+    assert done == 30 and seed2 == seed
+    _, more, _ = renderer.render(cam, rt.make_params(w, h, 100 - done, sample_begin=done, seed=seed2))
+    total = fix + more
+    fb, _, _ = oracle_mod.render_b(oracle_mod.camera_from_host(cam), book1_flat, oracle_mod.make_params(w, h, 100, seed=seed))
+    assert np.array_equal(total, fb)
+    assert np.array_equal(renderer.resolve_rgba8(total, 100), oracle_mod.resolve_b(fb, 100))
