@@ -73,3 +73,28 @@ def test_recorded_bench_line_has_the_contracts_fields():
     if cfg["kernel_source_sha"] != bench.kernel_source_sha():
         import pytest
         pytest.skip("profiles/r03_bench_n1.json was recorded on other kernel sources (%s)" % cfg["kernel_source_sha"])
+
+
+def test_rmse_helper_on_the_two_oracles():
+    """bench.rmse_vs_cpu (the second half of BASELINE.json's metric) on CPU data: Oracle B's exact sums stand in for the GPU's
+    (they are what the GPU must reproduce bit for bit), Oracle A is the CPU render: RMSE of the linear means ~1e-10, RGBA8
+    bytes identical; and the helper notices a frame that is off by one sample in one pixel."""
+    import numpy as np
+    import oracle
+    import rtiow_amd as rt
+    flat = rt.random_scene(1).flatten()
+    w, h, spp = 64, 36, 8
+    cam = oracle.book1_camera(w, h)
+    p = oracle.make_params(w, h, spp, rows=(0, h, 3))
+    fix, _, _ = oracle.render_b(cam, flat, p)
+    sums, _ = oracle.render_a(cam, flat, p)
+    rgba = oracle.resolve_b(fix, spp, flip=False)
+    par = bench.rmse_vs_cpu(fix, rgba, sums, spp)
+    assert par["rmse"] < 1e-9 and par["rgba8_rows_identical"] is True and par["rgba8_bytes_differing"] == 0
+    bad = fix.copy()
+    bad[2, 5, 1] += np.uint64(1 << 32)                                   # one more unit of radiance in one channel of one pixel
+    par = bench.rmse_vs_cpu(bad, rgba, sums, spp)
+    assert par["max_abs_diff"] > 0.12 and par["rmse"] > 1e-4
+    cb, rows_j, cpu_sums = bench.cpu_baseline(flat, w, h, spp, target_seconds=0.2, min_rows=10)
+    assert len(rows_j) == cpu_sums.shape[0] >= 10 and cb["kind"] == "port" and cb["value"] > 0
+    assert np.array_equal(rows_j, np.arange(0, h, rows_j[1] - rows_j[0])[:len(rows_j)])
