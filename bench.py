@@ -130,6 +130,13 @@ def rmse_vs_cpu(gpu_fix_rows, gpu_rgba_rows_bottom_up, cpu_sums, spp):
     }
 
 
+def kernel_name(scan_mode, kernel_variant):
+    """The instantiation rt_stats names, spelled as rocprofv3's kernel trace spells it: render_kernel<MODE, DIAG, SMALLGRID, U53>
+    (rt_stats.kernel_variant: bit 0 = the small-grid kernel, bit 1 = 53-bit uniforms; bench.py never sets RT_FLAG_DIAG_STATS)."""
+    b = lambda x: "true" if x else "false"
+    return f"rt::render_kernel<{int(scan_mode)}, false, {b(kernel_variant & 1)}, {b(kernel_variant & 2)}>"
+
+
 def launch_command(n_ranks, port, argv):
     """The child command of a self-launch: N ranks of this file under torch.distributed.run."""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
@@ -210,14 +217,20 @@ def main():
     dist = None
     if args.rehearse_on_one_gpu:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
     if world > 1:
+        # (the rendezvous comes BEFORE anything touches the GPU: a rank that cannot join fails here, on any box)
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # An explicit timeout: a rank that never arrives (or dies inside a step) ends the run non-zero within two
+        # minutes instead of holding the others for torch's default (10 min for RCCL, 30 min for gloo).  A step of the
+        # N > 1 workload is ~0.6 s; RTIOW_DIST_TIMEOUT_S overrides.
+        dist_timeout = datetime.timedelta(seconds=float(os.environ.get("RTIOW_DIST_TIMEOUT_S", "120")))
         if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=dist_timeout)
         else:
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            dist.init_process_group("nccl", timeout=dist_timeout, device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
 
     default_whs = (1200, 675, 500) if world == 1 else (7680, 4320, 125)
     if args.weak_baseline:
@@ -355,7 +368,8 @@ def main():
             #              MI355X_MICROARCH.md's constants); `peak_uniform` = 1024 x 2.4 / 2, every instruction at 2 cycles;
             #   frac     = achieved / peak;  `valu_busy` = the measured share of SIMD cycles in which a vector
             #              instruction is issuing (SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles)) -- a utilisation, not a roofline.
-            "bound": "valu-issue", "kernel": f"rt::render_kernel<{step.scan_mode}, false, {'true' if step.kernel_variant & 1 else 'false'}>",
+            # (all four template arguments <MODE, DIAG, SMALLGRID, U53>: the name rocprofv3's kernel trace prints)
+            "bound": "valu-issue", "kernel": kernel_name(step.scan_mode, step.kernel_variant),
             "achieved": None, "peak": None, "unit": "G vector wave-instructions/s", "frac": None,
             "kernel_ms": round(k_ms, 3), "kernel_ms_source": "HIP events on the launch stream, this run",
             "launches_timed": len(kernel_ms),

@@ -5,6 +5,7 @@
 //   rtiow_render [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--scene-seed S]
 //                [--grid LO HI] [--device K] [--out image.ppm] [--dump-scene scene.bin] [--scene scene.bin]
 //                [--devices 0,1,..  [--tile-rows T] [--force-rccl]] [--uniform53]
+//   rtiow_render --reassembly-plan H T N     (no GPU: the strided copies that put N shards' rows back in image order)
 //
 // --devices: the frame's rows are dealt round-robin to one rt_context per listed device, each driven by
 // its own host thread, and gathered with ONE RCCL ncclGather to the first device (host/rtiow_multi.hpp).
@@ -33,6 +34,14 @@ int main(int argc, char **argv)
     std::vector<int> devices;                    // --devices 0,1,...: one context + host thread per entry
     bool force_rccl = false, uniform53 = false;
     int tile_rows = 1;
+    if (argc == 5 && !std::strcmp(argv[1], "--reassembly-plan")) {
+        const int H = std::atoi(argv[2]), T = std::atoi(argv[3]), n = std::atoi(argv[4]);
+        if (H < 1 || T < 1 || n < 1) { std::fprintf(stderr, "--reassembly-plan H T N: all >= 1\n"); return 2; }
+        for (int k = 0; k < n; ++k)
+            for (const rtiow::RowCopy &c : rtiow::reassembly_plan(H, T, n, k))
+                std::printf("%d %d %d %d %d %d %d\n", k, c.dst_row, c.src_row, c.rows, c.pieces, c.dst_pitch_rows, c.src_pitch_rows);
+        return 0;
+    }
     for (int i = 1; i < argc; ++i) {
         auto arg = [&](const char *n) { return !std::strcmp(argv[i], n) && i + 1 < argc; };
         if (arg("--width")) width = std::atoi(argv[++i]);
@@ -87,10 +96,12 @@ int main(int argc, char **argv)
         // one RCCL gather of the exact sums to the first device (main.rs:122-123 + the ordered collect() :139)
         p.tile_rows = tile_rows;
         std::string err;
-        if (rtiow::render_sharded(devices, force_rccl, flat, rc_cam, p, rgba.data(), &st, &err)) {
+        int copy_calls = 0;
+        if (rtiow::render_sharded(devices, force_rccl, flat, rc_cam, p, rgba.data(), &st, &err, &copy_calls)) {
             std::fprintf(stderr, "render_sharded failed: %s\n", err.c_str());
             return 1;
         }
+        std::printf("%zu shards, tiles of %d rows: %d device copies put the rows back in image order\n", devices.size(), tile_rows, copy_calls);
     } else {
         rt_context *ctx = nullptr;
         int rc = rt_create(device, &ctx);

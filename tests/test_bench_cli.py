@@ -18,6 +18,29 @@ def test_self_launch_command_is_a_torchrun_child_on_loopback():
     assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
 
 
+def test_kernel_name_carries_all_four_template_arguments():
+    """roofline.kernel must join with rocprofv3's kernel trace by name: render_kernel<MODE, DIAG, SMALLGRID, U53>."""
+    assert bench.kernel_name(5, 1) == "rt::render_kernel<5, false, true, false>"       # the shipped small-grid kernel
+    assert bench.kernel_name(5, 0) == "rt::render_kernel<5, false, false, false>"      # large grids (10k spheres)
+    assert bench.kernel_name(5, 3) == "rt::render_kernel<5, false, true, true>"        # RT_FLAG_UNIFORM53
+    assert bench.kernel_name(0, 2) == "rt::render_kernel<0, false, false, true>"
+
+
+def test_a_rank_that_never_arrives_ends_the_run_within_the_timeout():
+    """bench.py gives init_process_group an explicit timeout (RTIOW_DIST_TIMEOUT_S, default 120 s): with WORLD_SIZE=2 and
+    only rank 0 started, the rendezvous must give up non-zero after that time, not after torch's 10-30 minute defaults.
+    (gloo rehearsal path; the rendezvous comes before anything touches a GPU, so this runs on any box.)"""
+    import socket
+    import time
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RTIOW_DIST_TIMEOUT_S="5")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "1",
+                        "--warmup", "0"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and time.time() - t0 < 90, (r.returncode, r.stderr[-500:])
+    assert "imeout" in r.stderr or "timed out" in r.stderr, r.stderr[-800:]
+
+
 def test_help_needs_neither_torch_nor_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "--rehearse-on-one-gpu" in r.stdout

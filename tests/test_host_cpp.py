@@ -53,13 +53,15 @@ def test_cpp_cli_reads_a_scene_file(tmp_path, renderer):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [["--devices", "0,0"], ["--devices", "0,0,0", "--tile-rows", "7"],
-                                   ["--devices", "0", "--force-rccl"]])
-def test_cpp_sharded_render_equals_the_single_context_image(tmp_path, extra):
+@pytest.mark.parametrize("extra,copies", [(["--devices", "0,0"], 2), (["--devices", "0,0,0", "--tile-rows", "7"], 4),
+                                          (["--devices", "0", "--force-rccl"], 1), (["--devices", "0,0,0,0,0", "--tile-rows", "40"], 5)])
+def test_cpp_sharded_render_equals_the_single_context_image(tmp_path, extra, copies):
     """host/rtiow_multi.hpp: one rt_context per listed device, each on its own host thread (here: two or three
     contexts on device 0 rendering their shards CONCURRENTLY -- the threading rule of include/rtiow_hip.h:
     distinct contexts may be used from distinct threads at the same time), rows gathered and put back in
-    image order, one resolve.  The result must be the single-context image byte for byte.  A list of distinct
+    image order -- ONE 2D device copy per shard plus one for a ragged last tile (169 rows: 24 tiles of 7 + 1 row; 4 tiles
+    of 40 + 9 rows, so the fifth shard owns the ragged tile only), not one per tile -- one resolve.  The result must be
+    the single-context image byte for byte.  A list of distinct
     devices gathers with RCCL ncclGather; with one GPU here that path runs as a communicator of one
     (--force-rccl)."""
     single, sharded = str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm")
@@ -68,6 +70,38 @@ def test_cpp_sharded_render_equals_the_single_context_image(tmp_path, extra):
     r = subprocess.run([_cli(), *size, *extra, "--out", sharded], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert open(single, "rb").read() == open(sharded, "rb").read()
+    assert f": {copies} device copies" in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("H,T,n", [(169, 7, 3), (169, 1, 2), (169, 40, 5), (4320, 1, 8), (4320, 16, 8), (675, 8, 1), (5, 8, 3), (10, 3, 4)])
+def test_cpp_reassembly_plan_is_the_inverse_of_the_shard_row_map(H, T, n):
+    """host/rtiow_multi.hpp reassembly_plan(): the strided copies rank 0 issues must send compact row c of shard k to
+    image row rt_shard_row_index(c) -- every image row exactly once -- with at most two copies per shard (one 2D copy for
+    the shard's full tiles, one for a ragged last tile): 8 calls for 7680x4320 on 8 GPUs at tiles of one row, not 4 320."""
+    from rtiow_amd import render as rr
+    from rtiow_amd.distributed import shard_row_map
+    out = subprocess.run([_cli(), "--reassembly-plan", str(H), str(T), str(n)], check=True, capture_output=True, text=True).stdout
+    plan = [tuple(int(x) for x in line.split()) for line in out.splitlines()]
+    assert len(plan) <= n + 1 and all(sum(1 for e in plan if e[0] == k) <= 2 for k in range(n))
+    if (H, T, n) == (4320, 1, 8):
+        assert len(plan) == 8
+    owner = -np.ones(H, dtype=np.int64)
+    for k in range(n):
+        # image row of every compact row of shard k: the library's own map (rt_shard_row_index) == the Python gatherer's
+        rows = rr.shard_row_indices(rr.make_params(16, H, 1, tile_rows=T, shard_index=k, shard_count=n))
+        assert np.array_equal(rows, shard_row_map(H, T, k, n))
+        got = -np.ones(len(rows), dtype=np.int64)
+        for (kk, dst, src, cnt, pieces, dp, sp) in plan:
+            if kk != k:
+                continue
+            for i in range(pieces):
+                for r in range(cnt):
+                    assert got[src + i * sp + r] == -1
+                    got[src + i * sp + r] = dst + i * dp + r
+        assert np.array_equal(got, np.asarray(rows))
+        assert np.all(owner[np.asarray(rows, dtype=np.int64)] == -1)
+        owner[np.asarray(rows, dtype=np.int64)] = k
+    assert np.all(owner >= 0)
 
 
 @pytest.mark.parametrize("devices", ["0,99", "99", "0,0,99"])
