@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# ORACLE_LIB: another build of the same sources (tests/test_sanitizers.py points it at the ASan/UBSan build)
+LIB_PATH = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
 
 
 class sphere(C.Structure):
@@ -41,7 +42,7 @@ _lib = None
 
 
 def build():
-    subprocess.run(["make", "-s", "-C", _HERE, "liboracle.so"], check=True)
+    subprocess.run(["make", "-s", "-C", _HERE, os.path.basename(LIB_PATH)], check=True)
 
 
 def load():
