@@ -143,6 +143,11 @@ int rt_create(int32_t device_id, rt_context **out);
 int rt_destroy(rt_context *ctx);
 
 /* ---- scene: stands in for `&world` captured at main.rs:135 ----------------- */
+/* The reference's list is a Vec<Box<dyn Hit>> of any length (shapes/mod.rs:52).  Here n <= RT_MAX_SPHERES: the
+ * kernel numbers the columns of its filter table in 26 bits, and a table holds at most ~2 columns per sphere.
+ * (Rounds 1-3 stopped at 65 535: 16-bit candidate numbers.)  Coordinates and radii must be finite and below
+ * 1e15 in magnitude, radii non-zero, kinds RT_LAMBERTIAN / RT_METAL / RT_DIALECTRIC. */
+#define RT_MAX_SPHERES (1 << 24)
 int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n);
 
 /* Rows owned by (shard_index, shard_count, tile_rows) of an image `height`
@@ -151,6 +156,18 @@ int rt_shard_rows(const rt_params *p, int32_t *out_rows);
 int rt_shard_row_index(const rt_params *p, int32_t compact_row, int32_t *out_j);
 
 /* ---- the hot path: main.rs:122-139 up to (not including) to_rgba ----------- */
+
+/* The exact sums and their range (contract C5).  The reference adds every sample's colour into an f64 per pixel
+ * (main.rs:127,135), unbounded.  Here one channel of one sample enters the pixel's sum as
+ *     q = floor(min(x, RT_SAMPLE_CLAMP) * 2^32)   (0 for a NaN or a negative x)
+ * and the sums are u64: exact, associative, identical however the samples are spread over lanes, launches or GPUs.
+ * With q <= 2^48 a sum CANNOT wrap while a pixel has received at most 65 536 samples (all launches that accumulate
+ * into the same buffer together), whatever the scene; and within that limit the clamp cannot change a byte of
+ * Color::to_rgba: a clamped sample alone puts the pixel's mean at >= 1, i.e. at byte 255, where the reference's
+ * unbounded sum puts it too.  Beyond 65 536 samples per pixel the sums stay exact while the pixel's mean radiance is
+ * below 2^32 / samples; a scene whose albedos are <= 1 (every scene of the reference) has x <= 1 and no limit below
+ * 2^32 samples.  (Rounds 1-3 clamped at 2^30: four saturated samples wrapped a sum.) */
+#define RT_SAMPLE_CLAMP 65536.0
 
 /* Host-buffer form.  out_sum: [rows][width][3] f32 radiance SUMS over the spp
  * samples (divide by spp for the mean), rows = rt_shard_rows().  out_fix
@@ -196,7 +213,7 @@ const char *rt_build_source_sha(void);
 int rt_f64_div_sqrt_device(rt_context *ctx, const double *a, const double *b, int32_t n,
                            double *out_div, double *out_sqrt);
 /* ... and the kernel's quantisation of one radiance channel to the exact 2^-32 grid (contract C5, DESIGN.md
- * section 4): out[i] = floor(min(x[i], 2^30) * 2^32) for x[i] >= 0, and 0 for negatives and NaN. */
+ * section 4): out[i] = floor(min(x[i], RT_SAMPLE_CLAMP) * 2^32) for x[i] >= 0, and 0 for negatives and NaN. */
 int rt_quantize_device(rt_context *ctx, const double *x, int32_t n, uint64_t *out);
 /* Known-answer hooks of the EARLIER matrix-pipe forms of the filter (scan modes 2-4).
  * They exist only in a library built with -DRTIOW_CROSSCHECK_MODES (tools/librtiow_hip_xcheck.so, a test

@@ -13,7 +13,7 @@
  *       attenuations multiply into a running throughput left to right and
  *       the sky colour is multiplied by the throughput at the end;
  *   C5  an exact pixel sum: each sample's radiance channel x is truncated to
- *       the 2^-32 grid, q = trunc(clamp(x, 0, 2^30) * 2^32) (NaN -> 0), and
+ *       the 2^-32 grid, q = trunc(clamp(x, 0, 2^16) * 2^32) (NaN -> 0), and
  *       summed in a u64 (associative: any order or sharding of the samples
  *       gives the same bits).
  * B calls the very same sphere_hit / world_hit / scatter / get_ray functions
@@ -278,7 +278,7 @@ static vec3 ray_color_iter(ray r, trace_ctx *cx, oracle_rng *rng)
 uint64_t oracle_b_quantize(double x)
 {   /* C5 */
     if (!(x >= 0.0)) return 0;                  /* NaN and negatives */
-    if (x > 1073741824.0) x = 1073741824.0;     /* 2^30 */
+    if (x > 65536.0) x = 65536.0;               /* 2^16: include/rtiow_hip.h RT_SAMPLE_CLAMP */
     return (uint64_t)(x * 4294967296.0);        /* exact scaling, truncation */
 }
 

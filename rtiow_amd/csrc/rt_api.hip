@@ -320,6 +320,11 @@ int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, in
     return RT_OK;
 }
 
+// MODE 5 numbers candidates by table column in 26 bits (the pool word of rt_kernels.hpp is column << 6 | ray), and the
+// large-grid kernel keeps one 64-bit word per grid row in LDS with one lane per row (a run of columns is (1 << n) - 1 << x0).
+constexpr size_t kMaxColumns = (size_t)1 << 26;
+constexpr int kMaxGridDim = 63;
+
 // Where MODE 5 puts each sphere in its table of columns (tiles of 32), and the grid the kernel finds tiles with.
 struct TileLayout {
     int grid_dim = 0, n_global = 0;
@@ -409,7 +414,7 @@ TileLayout tile_layout(const rt_sphere *spheres, int n, const char *never)
         int G = one_cell ? 1 : env_int("RTIOW_GRID_DIM", 0);
         if (G <= 0) {
             double best = INFINITY;
-            for (int g = 1; g <= 42; ++g) {
+            for (int g = 1; g <= kMaxGridDim; ++g) {
                 if ((double)g * g > (double)filtered.size()) break;
                 const int ng = assign(g, false);
                 if (ng > 48) continue;                              // (the kernel's list holds 126 tiles)
@@ -417,7 +422,7 @@ TileLayout tile_layout(const rt_sphere *spheres, int n, const char *never)
                 if (cost < best) { best = cost; G = g; }
             }
         }
-        G = std::max(1, std::min(G, 42));                   // (no G qualified: G = 1 will not either, and the grid stays off)
+        G = std::max(1, std::min(G, kMaxGridDim));          // (no G qualified: G = 1 will not either, and the grid stays off)
         (void)assign(G, true);
         double ylo = INFINITY, yhi = -INFINITY, pad = 0.0;
         for (const std::vector<int> &c : cells)
@@ -428,7 +433,7 @@ TileLayout tile_layout(const rt_sphere *spheres, int n, const char *never)
             }
         const int n_global = (int)((global.size() + 31) / 32);
         const float inv_cell = (float)(1.0 / cell);
-        if (std::isnormal(inv_cell) && (size_t)(n_global + G * G) * 32 <= 65536 && n_global <= 48 && ylo <= yhi) {
+        if (std::isnormal(inv_cell) && (size_t)(n_global + G * G) * 32 <= (size_t)kMaxColumns && n_global <= 48 && ylo <= yhi) {
             L.grid_dim = G; L.n_global = n_global;
             slot_of.assign((size_t)(n_global + G * G) * 32, -1);
             for (size_t k = 0; k < global.size(); ++k) slot_of[k] = global[k];
@@ -535,7 +540,9 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
 {
     if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (n < 0 || (n > 0 && !spheres)) return fail(RT_ERR_INVALID_ARGUMENT, "bad sphere list");
-    if (n > 65535) return fail(RT_ERR_INVALID_ARGUMENT, "at most 65535 spheres (16-bit candidate indices)");
+    if (n > RT_MAX_SPHERES) return fail(RT_ERR_INVALID_ARGUMENT, "at most %d spheres (RT_MAX_SPHERES)", RT_MAX_SPHERES);
+    // (scan mode 1, the VALU cross-check filter, keeps 16-bit candidate lists in LDS)
+    if (ctx->scan_mode == 1 && n > 65535) return fail(RT_ERR_INVALID_ARGUMENT, "RTIOW_SCAN_MODE=1 (the cross-check filter) takes at most 65535 spheres");
     for (int i = 0; i < n; ++i) {
         const rt_sphere &s = spheres[i];
         if (s.kind < RT_LAMBERTIAN || s.kind > RT_DIALECTRIC)
@@ -1090,7 +1097,7 @@ int rt_filter_tube_device(rt_context *ctx, const double *o, const double *d, con
 
 int rt_tile_layout_host(const rt_sphere *spheres, int32_t n, int32_t out_dims[2], float out_grid[8], int32_t *out_slot_of, int32_t cap)
 {
-    if (!spheres || n < 0 || n > 65535 || !out_dims || !out_grid || (!out_slot_of && cap > 0)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_tile_layout_host: bad argument");
+    if (!spheres || n < 0 || n > RT_MAX_SPHERES || !out_dims || !out_grid || (!out_slot_of && cap > 0)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_tile_layout_host: bad argument");
     std::vector<char> never(n > 0 ? n : 1, 0);
     for (int i : always_exact_list(spheres, n)) never[i] = 1;
     const TileLayout L = tile_layout(spheres, n, never.data());

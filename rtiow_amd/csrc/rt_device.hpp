@@ -113,13 +113,15 @@ __device__ __forceinline__ bool unit_sphere_accepts(uint32_t wx, uint32_t wy, ui
     return (unsigned long long)(x * x + y * y + z * z) < (1ull << 46);
 }
 
-// Contract C5: truncate one radiance channel to the 2^-32 grid.
-// (= (unsigned long long)(x * 2^32) for 0 <= x <= 2^30, 0 for NaN and negatives, 2^62 above -- written so that it
+// Contract C5: truncate one radiance channel to the 2^-32 grid, clamped at 2^16 = kSampleClamp (include/rtiow_hip.h,
+// RT_SAMPLE_CLAMP: with q <= 2^48 a pixel's u64 sum cannot wrap below 65 536 samples, and below 65 536 samples a clamped
+// sample alone puts the pixel's mean at >= 1, i.e. at byte 255, where the reference's unbounded f64 sum puts it too).
+// (= (unsigned long long)(x * 2^32) for 0 <= x <= 2^16, 0 for NaN and negatives, 2^48 above -- written so that it
 //  compiles to 7 instructions instead of the 13 of a generic f64 -> u64 conversion: the integer part converts
 //  exactly (v_cvt_u32_f64 truncates), the rest x - hi is exact, and so is its product with 2^32)
 __device__ __forceinline__ unsigned long long quantize(double x)
 {
-    x = __builtin_fmin(__builtin_fmax(x, 0.0), 1073741824.0);       // NaN -> 0: maxNum(NaN, 0) is 0 (the max FIRST)
+    x = __builtin_fmin(__builtin_fmax(x, 0.0), 65536.0);            // NaN -> 0: maxNum(NaN, 0) is 0 (the max FIRST)
     const uint32_t hi = (uint32_t)x;
     const uint32_t lo = (uint32_t)((x - (double)hi) * 4294967296.0);
     return ((unsigned long long)hi << 32) | (unsigned long long)lo;

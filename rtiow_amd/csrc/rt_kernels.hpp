@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
     // the two accepted lens words, pixel, sample and (events drawn << 8 | pixel slot of the block): 36 bytes per entry.
     __shared__ double s_quv[kBlock / 64][2][64];
     __shared__ unsigned int s_qid[kBlock / 64][5][64];
-    // pooled exact tests: ring of waiting (ray << 16 | sphere) pairs per wave; per-ray minimum root and its sphere
+    // pooled exact tests: ring of waiting (column << 6 | ray) pairs per wave (columns < 2^26); per-ray minimum root and its sphere
     __shared__ unsigned int s_pool[MATRIX ? kBlock / 64 : 1][MATRIX ? 128 : 1];
     __shared__ unsigned long long s_best[MATRIX ? kBlock : 1];
     __shared__ unsigned int s_bidx[MATRIX ? kBlock : 1];
@@ -593,8 +593,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 RT_COUNT(5);
                 const uint32_t e_i = pool_done + (uint32_t)lane;
                 const bool act = e_i < pool_n;
-                const uint32_t e = act ? pool_w[e_i & 127u] : ((uint32_t)lane << 16);
-                const int r = (int)(e >> 16), slot = (int)(e & 0xFFFFu);
+                const uint32_t e = act ? pool_w[e_i & 127u] : (uint32_t)lane;
+                const int r = (int)(e & 63u), slot = (int)(e >> 6);         // (26 bits of column: 64 M columns)
                 // MODE 5 numbers candidates by their column in the table (spheres are tiled by position); everything
                 // the reference decides by a sphere's place in the list uses idx, the place in the caller's list
                 const int idx = TUBE ? (int)P.slot_orig[slot] : slot;
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                         const int bpos = __builtin_ctz(word);
                         word &= word - 1u;
                         const uint32_t pos = pool_n + rank_below(m);
-                        pool_w[pos & 127u] = ((uint32_t)lane << 16) | (uint32_t)(wbase + bpos);
+                        pool_w[pos & 127u] = ((uint32_t)(wbase + bpos) << 6) | (uint32_t)lane;
                     }
                     pool_n += (uint32_t)__popcll(m);
                     if (pool_n - pool_done >= 64u) pool_round();
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                         if (cnt == 0) nz = 0;
                         for (int k = 0; __any(k < nz); ++k)
                             if (k < nz) {
-                                int rx0, rnx;                                               // rnx + rx0 <= grid_dim <= 42
+                                int rx0, rnx;                                               // rnx + rx0 <= grid_dim <= 63
                                 grid_row_run(seg, P.grid_dim, iz0 + k, rx0, rnx);
                                 atomicOr(&tm[iz0 + k], ((1ull << rnx) - 1ull) << rx0);
                             }

@@ -46,6 +46,22 @@ def stats_dict(st):
     return out
 
 
+def tile_layout_host(flat):
+    """Where rt_upload_scene puts each sphere in the filter's table of columns (rt_tile_layout_host, no GPU):
+    ((grid_dim, n_global), grid[8] f32, slot_of[columns] i32 with -1 for padding)."""
+    lib = _ffi.load()
+    flat = np.ascontiguousarray(flat, dtype=SPHERE_DTYPE)
+    dims = (C.c_int32 * 2)()
+    grid = (C.c_float * 8)()
+    cap = 2 * len(flat) + (48 + 63 * 63) * 32 + 64
+    slot = np.full(cap, -2, dtype=np.int32)
+    n = lib.rt_tile_layout_host(flat.ctypes.data_as(C.POINTER(_ffi.rt_sphere)), len(flat), dims, grid,
+                                slot.ctypes.data_as(C.POINTER(C.c_int32)), len(slot))
+    if n < 0:
+        _ffi.check(n, "rt_tile_layout_host")
+    return (int(dims[0]), int(dims[1])), np.array(list(grid), dtype=np.float32), slot[:n].copy()
+
+
 def tube_tile_host(spheres32):
     """Host-side half of one tube-filter tile (no GPU): words (64, 4) u32, bound (32,) f32, rho."""
     lib = _ffi.load()

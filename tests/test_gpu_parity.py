@@ -148,21 +148,21 @@ def test_f64_divide_and_sqrt_are_correctly_rounded_on_device(renderer):
 
 
 def test_quantize_on_device_is_the_oracles(renderer, oracle_mod):
-    """Contract C5 on the device (rt_quantize_device runs the kernel's own quantize()): floor(min(x, 2^30) 2^32) for
+    """Contract C5 on the device (rt_quantize_device runs the kernel's own quantize()): floor(min(x, 2^16) 2^32) for
     x >= 0, 0 for negatives and NaN -- on the edge values and on 2^18 random radiances of every magnitude."""
     lib = oracle_mod.load()
     rng = np.random.default_rng(9)
     x = np.abs(rng.standard_normal(1 << 18)) * 10.0 ** rng.integers(-40, 12, 1 << 18)
     x[1::7] *= -1.0
-    edge = [0.0, -0.0, 1.0, 0.5, 2.0 ** -33, 2.0 ** -32, np.nextafter(2.0 ** -32, 0.0), 1.0 - 2.0 ** -53, 1e30, 2.0 ** 30,
-            np.nextafter(2.0 ** 30, 0.0), np.nextafter(2.0 ** 30, np.inf), np.inf, -np.inf, np.nan, -1.0, 5e-324, 4294967295.75,
+    edge = [0.0, -0.0, 1.0, 0.5, 2.0 ** -33, 2.0 ** -32, np.nextafter(2.0 ** -32, 0.0), 1.0 - 2.0 ** -53, 1e30, 2.0 ** 30, 2.0 ** 16,
+            np.nextafter(2.0 ** 16, 0.0), np.nextafter(2.0 ** 16, np.inf), np.inf, -np.inf, np.nan, -1.0, 5e-324, 4294967295.75,
             123456.789, 2.0 ** 29 + 2.0 ** -23]
     x[:len(edge)] = edge
     q = renderer.quantize(x)
     want = np.array([lib.oracle_b_quantize(float(v)) for v in x[:4096]], dtype=np.uint64)
     assert np.array_equal(q[:4096], want)
     # the rest against the definition in numpy (exact: scaling by 2^32, truncation)
-    xs = np.where(np.isnan(x) | (x < 0), 0.0, np.minimum(x, 2.0 ** 30))
+    xs = np.where(np.isnan(x) | (x < 0), 0.0, np.minimum(x, 2.0 ** 16))
     ref = np.floor(xs).astype(np.uint64) * np.uint64(1 << 32) + np.floor((xs - np.floor(xs)) * 2.0 ** 32).astype(np.uint64)
     assert np.array_equal(q, ref)
 
@@ -176,10 +176,12 @@ def test_errors(renderer, book1_flat):
         bad["kind"][3] = 7
         with pytest.raises(rt.RtiowHipError, match="unknown material kind"):
             fresh.upload_scene(bad)
-        big = np.zeros(65536, dtype=rt.SPHERE_DTYPE)
-        big["radius"] = 1.0
-        with pytest.raises(rt.RtiowHipError, match="65535"):
-            fresh.upload_scene(big)
+        # more than RT_MAX_SPHERES (2^24): refused before the list is read (the count alone is enough)
+        import ctypes as C
+        from rtiow_amd import _ffi
+        few = np.ascontiguousarray(book1_flat[:4])
+        rc = fresh._lib.rt_upload_scene(fresh._h, few.ctypes.data_as(C.POINTER(_ffi.rt_sphere)), (1 << 24) + 1)
+        assert rc != 0 and b"RT_MAX_SPHERES" in fresh._lib.rt_last_error()
         nan = book1_flat.copy()
         nan["center"][2, 0] = np.inf
         with pytest.raises(rt.RtiowHipError, match="finite"):

@@ -21,15 +21,8 @@ f32 = np.float32
 
 
 def layout(flat):
-    lib = _ffi.load()
-    flat = np.ascontiguousarray(flat, dtype=rt.SPHERE_DTYPE)
-    dims = (C.c_int32 * 2)()
-    grid = (C.c_float * 8)()
-    slot = np.full(65536 + 64, -2, dtype=np.int32)
-    n = lib.rt_tile_layout_host(flat.ctypes.data_as(C.POINTER(_ffi.rt_sphere)), len(flat), dims, grid,
-                                slot.ctypes.data_as(C.POINTER(C.c_int32)), len(slot))
-    assert n >= 0, _ffi.last_error()
-    return int(dims[0]), int(dims[1]), np.array(list(grid), dtype=np.float32), slot[:n].copy()
+    (g, ng), grid, slot = rt.tile_layout_host(flat)
+    return g, ng, grid, slot
 
 
 def spheres(centers, radii):

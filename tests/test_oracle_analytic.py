@@ -164,7 +164,7 @@ def test_quantize_contract_c5(oracle_mod):
     assert q(0.0) == 0 and q(-1.0) == 0 and q(float("nan")) == 0
     assert q(1.0) == 1 << 32 and q(0.5) == 1 << 31
     assert q(2.0 ** -33) == 0 and q(2.0 ** -32) == 1
-    assert q(1e30) == 1 << 62                       # clamp at 2^30
+    assert q(1e30) == 1 << 48 and q(65536.0) == 1 << 48 and q(65535.5) == (65535 << 32) + (1 << 31)      # clamp at 2^16 (RT_SAMPLE_CLAMP)
     assert q(1.0 - 2.0 ** -53) == (1 << 32) - 1     # truncation, not rounding
 
 
