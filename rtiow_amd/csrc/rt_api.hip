@@ -857,7 +857,7 @@ int rt_last_stats(rt_context *ctx, rt_stats *stats)
     return RT_OK;
 }
 
-#if defined(RT_PHASE_STAMPS) || defined(RT_BLOCK_COUNTS) || defined(RT_EXIT_TIMES)
+#if defined(RT_PHASE_STAMPS) || defined(RT_BLOCK_COUNTS) || defined(RT_EXIT_TIMES) || defined(RT_LDS_CONFLICTS)
 extern "C" int rt_debug_phase_cycles(rt_context *ctx, unsigned long long out[8])
 {
     RT_HIP(hipSetDevice(ctx->device));

@@ -6,5 +6,6 @@ FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correct
 hipcc $FLAGS -DRT_PHASE_STAMPS -o tools/lib_stamps.so rtiow_amd/csrc/rt_api.hip &
 hipcc $FLAGS -DRT_BLOCK_COUNTS -o tools/lib_counts.so rtiow_amd/csrc/rt_api.hip &
 hipcc $FLAGS -DRT_EXIT_TIMES -o tools/lib_exit.so rtiow_amd/csrc/rt_api.hip &
+hipcc $FLAGS -DRT_LDS_CONFLICTS -o tools/lib_ldsc.so rtiow_amd/csrc/rt_api.hip &
 wait
 ls -la tools/lib_stamps.so tools/lib_counts.so tools/lib_exit.so
