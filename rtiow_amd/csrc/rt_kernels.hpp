@@ -33,6 +33,10 @@
 #include "rt_device.hpp"
 #include <type_traits>
 
+#ifndef RT_GROUP_SKIP
+#define RT_GROUP_SKIP 1     // MODE 5: a 16-ray group skips the tiles none of its rays can reach (0: every group scans the wave's whole list)
+#endif
+
 namespace rt {
 
 struct KCamera {
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
     if ((tid & 63) < 8) s_cnt[tid >> 6][tid & 7] = 0u;
 #define RT_STAMP(k) do { } while (0)
 #define RT_COUNT(k) do { if ((int)(tid & 63) == (int)__builtin_ctzll(__ballot(true))) s_cnt[tid >> 6][k] += 1u; } while (0)
+#define RT_COUNT_N(k, n) do { if ((int)(tid & 63) == (int)__builtin_ctzll(__ballot(true))) s_cnt[tid >> 6][k] += (unsigned)(n); } while (0)
 #elif defined(RT_LDS_CONFLICTS)
     // Diagnostic build only: modelled extra LDS cycles per site, into stats[8..15] (see lds_extra_cycles above):
     // 0 recording ds_or, 1 block-sum ds_add_u64, 2 pool ds_min_u64, 3 pool ds_max_u32 + reset, 4 ds_bpermute of the pool,
@@ -316,6 +321,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
 #else
 #define RT_STAMP(k) do { } while (0)
 #define RT_COUNT(k) do { } while (0)
+#endif
+#ifndef RT_COUNT_N
+#define RT_COUNT_N(k, n) do { } while (0)
 #endif
 #ifndef RT_LDS
 #define RT_LDS(site, BYTES, ATOMIC, LOAD64, ptr, active) do { } while (0)
@@ -735,7 +743,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                             summary &= summary - 1u;
                             word = bits_w[w * 64 + lane];
                             if constexpr (TUBE)         // seg0: position in the tile list of the segment's first tile
-                                wbase = 32 * (!SMALLGRID && list_all ? seg0 + w : (int)bits_w[(kSeg / 2) * 64 + seg0 + w]);
+                                wbase = 32 * (!SMALLGRID && list_all ? seg0 + w : (int)(bits_w[(kSeg / 2) * 64 + seg0 + w] & 0x0FFFFFFFu));
                             else
                                 wbase = 16 * seg0 + 32 * w;
                         }
@@ -847,6 +855,13 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast31 -> rows 2, 3
                     return __builtin_amdgcn_readlane(v, 63);
                 };
+                auto rows_or = [](int v) -> int {               // the OR over each row of 16 lanes (lane 16 g + 15 collects group g's)
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);    // row_shr:1
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);    // row_shr:2
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);    // row_shr:4
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);    // row_shr:8
+                    return v;
+                };
                 auto wave_scan_add = [](int v) -> int {         // inclusive prefix sum over the lanes (DPP)
                     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
                     v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
@@ -875,21 +890,48 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                             const unsigned long long rows = P.grid_rows & (~0ull >> (64 - nz * P.grid_dim));
                             m = (run * rows) << (iz0 * P.grid_dim);
                         }
+#if RT_GROUP_SKIP
+                        // ... and per 16-ray GROUP: a DPP row is 16 lanes, so after the four row steps lane 16 g + 15 holds group g's
+                        // cells; the wave's set is the OR of the four.  Each list entry carries, in its top four bits, which groups
+                        // can reach the tile: the tile loop skips the matrix instruction and the look of the others.
+                        // (skipping the high dword for grids of at most 32 cells -- the book scene's 4 x 4 -- measured SLOWER: 11.18 vs 11.10 ms)
+                        const int vlo = rows_or((int)(unsigned)m), vhi = rows_or((int)(unsigned)(m >> 32));
+                        unsigned mlo = 0u, mhi = 0u, gm = 0u;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const unsigned lo = (unsigned)__builtin_amdgcn_readlane(vlo, 16 * g + 15), hi = (unsigned)__builtin_amdgcn_readlane(vhi, 16 * g + 15);
+                            mlo |= lo; mhi |= hi;
+                            if (__builtin_amdgcn_inverse_ballot_w64(((unsigned long long)hi << 32) | lo)) gm |= 1u << g;    // (lane c: is cell c in group g's set)
+                        }
+                        const unsigned kAll = 0xF0000000u;
+#else
                         const unsigned mlo = (unsigned)wave_or((int)(unsigned)m), mhi = (unsigned)wave_or((int)(unsigned)(m >> 32));
+                        const unsigned gm = 0u, kAll = 0u;
+#endif
                         const unsigned long long cells = (((unsigned long long)mhi << 32) | mlo) & (~0ull >> (64 - gcells));
                         const int rank = (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-                        tl[lane] = (unsigned)(lane < P.n_global ? lane : ntt);      // (past the list: the spare tile)
-                        if (lane < 2) tl[64 + lane] = (unsigned)ntt;
+                        tl[lane] = (unsigned)(lane < P.n_global ? lane : ntt) | kAll;      // (past the list: the spare tile)
+                        if (lane < 2) tl[64 + lane] = (unsigned)ntt | kAll;
                         __builtin_amdgcn_wave_barrier();
-                        if ((cells >> lane) & 1ull) tl[P.n_global + rank] = (unsigned)(P.n_global + lane);
+                        if ((cells >> lane) & 1ull) tl[P.n_global + rank] = (unsigned)(P.n_global + lane) | (gm << 28);
                         __builtin_amdgcn_wave_barrier();
                         list_all = false;
                         n_list = P.n_global + __builtin_popcountll(cells);
                     } else if (!SMALLGRID && __ballot(cnt < 0) == 0ull) {
                         // a large grid: one 64-bit word per grid ROW in LDS, ORed by the rays; lane l then owns row l,
                         // a prefix sum over the rows' cell counts gives each row its place in the list
+#if RT_GROUP_SKIP
+                        // (one set of row words per 16-ray group, 2 KB of the bitmap area, free until the tile loop: each list entry
+                        //  then carries in its top four bits which groups can reach the tile)
+                        unsigned long long *tm = reinterpret_cast<unsigned long long *>(bits_w);   // [4][64]
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) tm[g * 64 + lane] = 0ull;
+                        unsigned long long *tm_g = tm + (lane >> 4) * 64;
+#else
                         unsigned long long *tm = reinterpret_cast<unsigned long long *>(bits_w);   // (512 B of the bitmap area, free until the tile loop)
                         tm[lane] = 0ull;
+                        unsigned long long *tm_g = tm;
+#endif
                         __builtin_amdgcn_wave_barrier();
                         // row by row: the columns of the part of the clipped piece that lies in the row's band (grid_row_run)
                         if (cnt == 0) nz = 0;
@@ -897,24 +939,36 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                             if (k < nz) {
                                 int rx0, rnx;                                               // rnx + rx0 <= grid_dim <= 63
                                 grid_row_run(seg, P.grid_dim, iz0 + k, rx0, rnx);
-                                atomicOr(&tm[iz0 + k], ((1ull << rnx) - 1ull) << rx0);
+                                atomicOr(&tm_g[iz0 + k], ((1ull << rnx) - 1ull) << rx0);
                             }
                         __builtin_amdgcn_wave_barrier();
+#if RT_GROUP_SKIP
+                        const unsigned long long w0 = tm[lane], w1 = tm[64 + lane], w2 = tm[128 + lane], w3 = tm[192 + lane];
+                        unsigned long long mw = (w0 | w1) | (w2 | w3);
+#else
                         unsigned long long mw = tm[lane];
+#endif
                         const int mine = __builtin_popcountll(mw);
                         const int upto = wave_scan_add(mine);
                         const int tn = P.n_global + __builtin_amdgcn_readlane(upto, 63);
                         if (tn <= kListCap) {
-                            if (lane < P.n_global) tl[lane] = (unsigned)lane;
+                            if (lane < P.n_global) tl[lane] = (unsigned)lane | (RT_GROUP_SKIP ? 0xF0000000u : 0u);
                             int pos = P.n_global + upto - mine;
                             const int row0 = P.n_global + lane * P.grid_dim;
                             while (__any(mw != 0ull)) {
                                 if (mw != 0ull) {
-                                    tl[pos++] = (unsigned)(row0 + __builtin_ctzll(mw));
+                                    const int b = __builtin_ctzll(mw);
+#if RT_GROUP_SKIP
+                                    const unsigned gm = (unsigned)((w0 >> b) & 1ull) | (unsigned)((w1 >> b) & 1ull) << 1 |
+                                                        (unsigned)((w2 >> b) & 1ull) << 2 | (unsigned)((w3 >> b) & 1ull) << 3;
+                                    tl[pos++] = (unsigned)(row0 + b) | (gm << 28);
+#else
+                                    tl[pos++] = (unsigned)(row0 + b);
+#endif
                                     mw &= mw - 1ull;
                                 }
                             }
-                            if (lane < 2) tl[tn + lane] = (unsigned)ntt;
+                            if (lane < 2) tl[tn + lane] = (unsigned)ntt | (RT_GROUP_SKIP ? 0xF0000000u : 0u);
                             __builtin_amdgcn_wave_barrier();
                             list_all = false;
                             n_list = tn;
@@ -922,7 +976,6 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     }
                 }
                 RT_STAMP(3);
-                if (list_all && P.grid_dim > 0) RT_COUNT(2);
                 RT_STAMP(5);
                 // waves in the tile loop issue ahead of their SIMD partners: the matrix pipe is fed sooner and the other
                 // waves' vector work fills the time the MFMAs take (measured: -1.4 % on configs[1])
@@ -931,13 +984,30 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     const int nwords = min(kSeg / 2, n_list - t0);          // one bitmap word per 32-sphere tile
                     for (int w = 0; w < nwords; ++w) bits_w[w * 64 + lane] = 0u;
                     // the segment's tiles (and two more for the look-ahead), one per lane
-                    const int listv = !SMALLGRID && list_all ? min(t0 + lane, ntt) : (int)tl[min(t0 + lane, kListCap + 1)];
-                    auto tile_at = [&](int j) -> int { return __builtin_amdgcn_readlane(listv, j); };      // j < 20, wave-uniform
+                    const int listv = !SMALLGRID && list_all ? (min(t0 + lane, ntt) | (RT_GROUP_SKIP ? (int)0xF0000000u : 0))
+                                                             : (int)tl[min(t0 + lane, kListCap + 1)];
+                    // j < 20, wave-uniform: the tile, and (top four bits) the 16-ray groups that can reach it
+                    auto tile_at = [&](int j) -> int { return __builtin_amdgcn_readlane(listv, j) & 0x0FFFFFFF; };
+                    auto groups_at = [&](int j) -> unsigned { return (unsigned)__builtin_amdgcn_readlane(listv, j) >> 28; };
                     __builtin_amdgcn_wave_barrier();
                     // one 32-sphere tile: four independent MFMAs (one per 16-ray group); two results in
                     // flight so the matrix pipe works on the next group while the VALU looks at this one
-                    auto do_tile = [&](int w, const bf16x8 &b) {
+                    auto do_tile = [&](int w, const bf16x8 &b, unsigned groups) {
                         RT_COUNT(7);
+                        RT_COUNT_N(2, __builtin_popcount(groups));      // (counter 2: matrix instructions + looks executed)
+#if RT_GROUP_SKIP
+                        if (groups != 0xFu) {
+                            // some groups cannot reach this tile (none of their rays' footprints holds its cell): only the others
+                            // go through the matrix pipe and the look
+#pragma unroll
+                            for (int G = 0; G < 4; ++G)
+                                if ((groups >> G) & 1u) {
+                                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[G], b, zero16, 0, 0, 0);
+                                    look_tube(G, acc, w);
+                                }
+                            return;
+                        }
+#endif
                         // (the empty asm pins the issue order: the scheduler would otherwise sink each MFMA
                         //  below the previous look to share registers, and the wave would sit out the full
                         //  matrix-pipe latency four times per tile)
@@ -954,18 +1024,16 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                         look_tube(3, acc1, w);
                     };
                     {
-                        // B operands ping-pong between two register sets, each fetched a tile ahead.  (All four 16-ray
-                        // groups go through the matrix pipe even when some hold no ray -- their rows keep nothing: a
-                        // second loop for the launch's last waves cost more in code than it saved, 1.8 % of the frame.)
+                        // B operands ping-pong between two register sets, each fetched a tile ahead.
                         bf16x8 bp = load_b(tile_at(0)), bq;
                         int w = 0;
                         for (; w + 1 < nwords; w += 2) {
                             bq = load_b(tile_at(w + 1));
-                            do_tile(w, bp);
+                            do_tile(w, bp, groups_at(w));
                             bp = load_b(tile_at(w + 2));
-                            do_tile(w + 1, bq);
+                            do_tile(w + 1, bq, groups_at(w + 1));
                         }
-                        if (w < nwords) do_tile(w, bp);
+                        if (w < nwords) do_tile(w, bp, groups_at(w));
                     }
                     __builtin_amdgcn_wave_barrier();
                     RT_STAMP(6);

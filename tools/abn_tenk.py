@@ -8,7 +8,7 @@ from rtiow_amd import _ffi
 import rtiow_amd as rt
 flat = np.ascontiguousarray(rt.random_scene(1, grid=(-50, 49)).flatten(), dtype=rt.SPHERE_DTYPE)
 cam = rt.book1_camera(1920, 1080).to_rt_camera()
-p = rt.make_params(1920, 1080, 32)
+p = rt.make_params(1920, 1080, int(os.environ.get("SPP", "32")))
 libs = []
 for path in sys.argv[1:]:
     lib = C.CDLL(os.path.abspath(path))

@@ -6,7 +6,7 @@ import torch  # noqa
 from rtiow_amd import _ffi
 _ffi.LIB_PATH = os.environ["RTIOW_LIB"]
 import rtiow_amd as rt
-names = ["bounce-loop passes", "camera block", "grid passes that scan every tile", "keep path (half-looks with a hit)",
+names = ["bounce-loop passes", "camera block", "16-ray group x tile: MFMA + look", "keep path (half-looks with a hit)",
          "keep path ray-group entries", "bitmap walk trips", "unit-sphere tries (wave level)", "tile iterations"]
 r = rt.Renderer(0)
 big = os.environ.get("SCENE") == "cfg4"
