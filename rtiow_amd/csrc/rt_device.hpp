@@ -358,7 +358,8 @@ __device__ __forceinline__ void lifted_stage_operands(uint4 *stage, int lane, co
 // and one instruction evaluates 16 rays x 2 directions against 32 spheres.  Soundness:
 // with the basis errors (|u_k.d^| <= 64u, ||u_k|-1| <= 64u, measured <= 8u), the operand truncation
 // (2^-16 per factor) and the accumulation (charged 2u per add on sum|terms|),
-//     hit  =>  |h_k| <= R + e,   R = r (1+64u) + 640u |c|   (per sphere),   e = 128u |o|   (per ray).
+//     hit  =>  |h_k| <= R + e,   R = r (1+64u) + 640u |c|   (per sphere),   e = 128u |o|_1   (per ray; the 1-norm
+//     |ox| + |oy| + |oz| >= |o| is two additions where the 2-norm is a correctly rounded f32 square root: 17 instructions).
 // The per-ray part is folded into the rows: they are scaled by lambda = rho / (rho + e), which makes
 // lambda |h_k| <= max(R, rho) for every sphere (rho: a per-scene radius floor chosen on the host).
 // The host folds each sphere's bound into its column: the column holds sigma c and sigma instead of c and 1, with
@@ -472,14 +473,14 @@ __device__ __forceinline__ TubeRay make_tube(D3 o, D3 d, float rho)
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
     const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
     const float a = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-    const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+    const float o1 = (__builtin_fabsf(ox) + __builtin_fabsf(oy)) + __builtin_fabsf(oz);        // |o|_1 >= |o|
     const float s = __builtin_amdgcn_rsqf(a);
     const float gx = dx * s, gy = dy * s, gz = dz * s;
     // orthonormal basis without a branch or a singular direction (Duff et al., JCGT 2017)
     const float sg = __builtin_copysignf(1.0f, gz);
     const float aa = -__builtin_amdgcn_rcpf(sg + gz);
     const float b = gx * gy * aa;
-    const float lam = rho * __builtin_amdgcn_rcpf(__builtin_fmaf(kTubeOriginErr, __builtin_sqrtf(oo), rho));
+    const float lam = rho * __builtin_amdgcn_rcpf(__builtin_fmaf(kTubeOriginErr, o1, rho));
     T.u[0][0] = lam * __builtin_fmaf(sg * gx, gx * aa, 1.0f);
     T.u[0][1] = lam * (sg * b);
     T.u[0][2] = lam * (-sg * gx);
@@ -489,7 +490,7 @@ __device__ __forceinline__ TubeRay make_tube(D3 o, D3 d, float rho)
 #pragma unroll
     for (int k = 0; k < 2; ++k)
         T.t[k] = -__builtin_fmaf(T.u[k][2], oz, __builtin_fmaf(T.u[k][1], oy, T.u[k][0] * ox));
-    T.sane = (a > 1e-20f) && (a < 1e20f) && (oo < 1e30f);
+    T.sane = (a > 1e-20f) && (a < 1e20f) && (o1 < 1e15f);           // (|o| <= |o|_1 < 1e15: |o|^2 < 1e30, the analysed range)
     if (!T.sane) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) { T.u[k][0] = T.u[k][1] = T.u[k][2] = 0.0f; T.t[k] = 3.0e38f; }

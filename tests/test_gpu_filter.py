@@ -71,7 +71,7 @@ def test_tube_filter_is_sound_and_within_its_budget(renderer):
         t = rows[:, 6:8].astype(np.float64)
         dn = d / np.linalg.norm(d, axis=1)[:, None]
         on = np.linalg.norm(o, axis=1)
-        lam = rho / (rho + 128.0 * U * on)
+        lam = rho / (rho + 128.0 * U * np.abs(o).sum(1))          # e = 128 u |o|_1 (the 1-norm bounds the 2-norm: rt_device.hpp, make_tube)
         # (1) the basis: lambda u_k is perpendicular to the ray and of length lambda, to well inside 64 u
         worst_basis = max(worst_basis, float(np.max(np.abs((u * dn[:, None, :]).sum(2)) / lam[:, None]) / U))
         worst_norm = max(worst_norm, float(np.max(np.abs(np.linalg.norm(u, axis=2) / lam[:, None] - 1.0)) / U))

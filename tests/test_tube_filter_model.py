@@ -34,13 +34,13 @@ def ulp_jitter(x, rng):
 def model_rows(o, d, rho, rng):
     of, df = o.astype(f32), d.astype(f32)
     a = (df[:, 2] * df[:, 2] + (df[:, 1] * df[:, 1] + df[:, 0] * df[:, 0])).astype(f32)
-    oo = (of[:, 2] * of[:, 2] + (of[:, 1] * of[:, 1] + of[:, 0] * of[:, 0])).astype(f32)
+    o1 = ((np.abs(of[:, 0]) + np.abs(of[:, 1])).astype(f32) + np.abs(of[:, 2])).astype(f32)      # |o|_1 >= |o| (rt_device.hpp, make_tube)
     s = ulp_jitter((f32(1.0) / np.sqrt(a.astype(np.float64))).astype(f32), rng)
     g = (df * s[:, None]).astype(f32)
     sg = np.where(np.signbit(g[:, 2]), f32(-1.0), f32(1.0)).astype(f32)
     aa = (-ulp_jitter((f32(1.0) / (sg + g[:, 2]).astype(np.float64)).astype(f32), rng)).astype(f32)
     b = ((g[:, 0] * g[:, 1]).astype(f32) * aa).astype(f32)
-    e = (f32(128 * U) * np.sqrt(oo.astype(np.float64)).astype(f32) + f32(rho)).astype(f32)
+    e = (f32(128 * U) * o1 + f32(rho)).astype(f32)
     lam = (f32(rho) * ulp_jitter((f32(1.0) / e.astype(np.float64)).astype(f32), rng)).astype(f32)
     u = np.empty((len(o), 2, 3), dtype=f32)
     u[:, 0, 0] = lam * ((sg * g[:, 0]).astype(f32) * (g[:, 0] * aa).astype(f32) + f32(1.0)).astype(f32)
