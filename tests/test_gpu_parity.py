@@ -143,8 +143,22 @@ def test_f64_divide_and_sqrt_are_correctly_rounded_on_device(renderer):
     a = np.abs(rng.standard_normal(1 << 18)) * 10.0 ** rng.integers(-30, 30, 1 << 18)
     b = rng.standard_normal(1 << 18) * 10.0 ** rng.integers(-30, 30, 1 << 18)
     a[:4] = [0.0, 1.0, 2.0, np.nextafter(1.0, 2.0)]
-    q, s = renderer.f64_div_sqrt(a, b)
-    assert np.array_equal(q, a / b) and np.array_equal(s, np.sqrt(a))
+
+    # argument (positive normal >= 2^-767) and the full expansion otherwise: both paths, and the edges between them
+    thr = 2.0 ** -767
+    special = [np.inf, 5e-324, 2.2250738585072014e-308, np.nextafter(2.2250738585072014e-308, 0.0), thr, np.nextafter(thr, 0.0),
+               np.nextafter(thr, 1.0), 1e-300, 1e300, 1.7976931348623157e308, -0.0]
+    a[4:4 + len(special)] = special
+    a[6400] = thr; a[12800] = np.nextafter(thr, 1.0)
+    a[19200] = np.nextafter(thr, 0.0); a[25600] = 0.0; a[32000] = np.inf
+    with np.errstate(all="ignore"):
+        q, s = renderer.f64_div_sqrt(a, b)
+        assert np.array_equal(q, a / b) and np.array_equal(s, np.sqrt(a))
+        # negative and NaN arguments: NaN out
+        neg = a.copy(); neg[100::977] *= -1.0; neg[50000] = np.nan
+        _, s2 = renderer.f64_div_sqrt(neg, b)
+        want = np.sqrt(neg)
+        assert np.array_equal(np.isnan(s2), np.isnan(want)) and np.array_equal(s2[~np.isnan(want)], want[~np.isnan(want)])
 
 
 def test_quantize_on_device_is_the_oracles(renderer, oracle_mod):

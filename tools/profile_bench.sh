@@ -1,7 +1,8 @@
 #!/bin/bash
 # Profiles `bench.py` on the GPU box: kernel trace + stats, then PMC passes (each in its own run, no trace
 # domains mixed with --pmc).  Three configurations: the bench default (1200x675x500, tag "target"),
-# BASELINE configs[1] (1200x675x100, tag "cfg2") and configs[3] (10k spheres, 1920x1080x256, tag "tenk": the large-grid kernel).  Output under gpurun_out/prof_<tag>/; summaries are copied
+# BASELINE configs[1] (1200x675x100, tag "cfg2"), configs[3] (10k spheres, 1920x1080x256, tag "tenk": the large-grid kernel) and
+# configs[2] (3840x2160x500, tag "weak": the N = 1 half of the weak-scaling pair, `bench.py --weak-baseline`).  Output under gpurun_out/prof_<tag>/; summaries are copied
 # into profiles/ by tools/summarize_profile.py.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -9,7 +10,8 @@ run_cfg() {
   TAG=$1; shift
   OUT=gpurun_out/prof_$TAG
   rm -rf $OUT; mkdir -p $OUT
-  ARGS="bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-other-configs $@"
+  STEPS=5; [ "$TAG" = weak ] && STEPS=2
+  ARGS="bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-other-configs $@"
   echo "$ARGS" > $OUT/command.txt
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
   echo "$TAG trace rc=$?"
@@ -28,3 +30,4 @@ run_cfg() {
 run_cfg target
 run_cfg cfg2 --width 1200 --height 675 --spp 100
 run_cfg tenk --tenk
+run_cfg weak --weak-baseline

@@ -4,12 +4,12 @@ profiles/<tag>_rocprofv3_<cfg>.json, profiles/<tag>_kernel_stats_<cfg>.csv and p
 kernel sources they were measured on -- bench.py nulls them when the sources have changed)."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 import bench  # noqa: E402  (kernel_source_sha)
 
-CONFIGS = {"target": [1200, 675, 500, 1], "cfg2": [1200, 675, 100, 1], "tenk": [1920, 1080, 256, 1]}
+CONFIGS = {"target": [1200, 675, 500, 1], "cfg2": [1200, 675, 100, 1], "tenk": [1920, 1080, 256, 1], "weak": [3840, 2160, 500, 1]}
 entries = []
 for cfg, shape in CONFIGS.items():
     prof = os.path.join(root, "gpurun_out", f"prof_{cfg}")
