@@ -63,7 +63,7 @@ def test_recorded_bench_line_has_the_contracts_fields():
     """The line recorded in profiles/ (this round's last `python bench.py --steps 20 --warmup 5` on an MI355X) carries every
     field the driver and the judge read, and its roofline numbers are consistent with each other."""
     import json
-    path = os.path.join(ROOT, "profiles", "r03_bench_n1.json")
+    path = os.path.join(ROOT, "profiles", "r04_bench_n1.json")
     d = json.loads(open(path).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "rmse_vs_cpu", "parity_vs_cpu"):
@@ -95,7 +95,7 @@ def test_recorded_bench_line_has_the_contracts_fields():
     #  nulls the replayed counters when the sources have moved on)
     if cfg["kernel_source_sha"] != bench.kernel_source_sha():
         import pytest
-        pytest.skip("profiles/r03_bench_n1.json was recorded on other kernel sources (%s)" % cfg["kernel_source_sha"])
+        pytest.skip("profiles/r04_bench_n1.json was recorded on other kernel sources (%s)" % cfg["kernel_source_sha"])
 
 
 def test_rmse_helper_on_the_two_oracles():
