@@ -417,16 +417,16 @@ __device__ __forceinline__ void grid_row_run(const GridSeg &s, int G, int iz, in
     nx = min(max((int)__builtin_floorf(hi), 0), G - 1) - ix0 + 1;
 }
 
-__device__ __forceinline__ int grid_cells(D3 o, D3 d, const float (&g)[8], int G, float scale, int &ix0, int &nx, int &iz0, int &nz,
-                                          GridSeg *seg = nullptr)
+// (of, df: the ray's origin and direction rounded to f32, o1 = |of|_1 -- shared with make_tube)
+__device__ __forceinline__ int grid_cells(const float (&of)[3], const float (&df)[3], float o1, const float (&g)[8], int G, float scale,
+                                          int &ix0, int &nx, int &iz0, int &nz, GridSeg *seg = nullptr)
 {
-    const float of[3] = {(float)o.x, (float)o.y, (float)o.z};
-    const float df[3] = {(float)d.x, (float)d.y, (float)d.z};
-    const float o1 = __builtin_fabsf(of[0]) + __builtin_fabsf(of[1]) + __builtin_fabsf(of[2]);
     const float e = 1e-6f * (o1 + scale);
     const float dmin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(df[0]), __builtin_fabsf(df[1])), __builtin_fabsf(df[2]));
     const float dmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(df[0]), __builtin_fabsf(df[1])), __builtin_fabsf(df[2]));
-    if (!(dmin > 1e-30f && dmax < 1e15f && o1 < 1e15f)) return -1;
+    // ONE exit: everything below is computed whatever the answer (garbage in, clamped garbage out) and the verdict is
+    // selected at the end -- four early returns cost five register moves each
+    const bool cannot0 = !(dmin > 1e-30f && dmax < 1e15f && o1 < 1e15f);
     const float m = g[7] + e;
     const float lo[3] = {g[0] - m, g[5] - e, g[1] - m}, hi[3] = {g[3] + m, g[6] + e, g[4] + m};
     float t_in = 0.0f, t_out = __builtin_inff();
@@ -437,14 +437,14 @@ __device__ __forceinline__ int grid_cells(D3 o, D3 d, const float (&g)[8], int G
         t_in = __builtin_fmaxf(t_in, __builtin_fminf(t0, t1));
         t_out = __builtin_fminf(t_out, __builtin_fmaxf(t0, t1));
     }
-    if (t_out < t_in * 0.9999f) return 0;
-    if (!(t_out < 1e30f)) return -1;
+    const bool empty = t_out < t_in * 0.9999f;
+    bool cannot1 = !(t_out < 1e30f);
     const float m2 = g[7] + 4.0f * e;
     const float xa = __builtin_fmaf(t_in, df[0], of[0]), xb = __builtin_fmaf(t_out, df[0], of[0]);
     const float za = __builtin_fmaf(t_in, df[2], of[2]), zb = __builtin_fmaf(t_out, df[2], of[2]);
     const float fx0 = ((__builtin_fminf(xa, xb) - m2) - g[0]) * g[2] - 1e-3f, fx1 = ((__builtin_fmaxf(xa, xb) + m2) - g[0]) * g[2] + 1e-3f;
     const float fz0 = ((__builtin_fminf(za, zb) - m2) - g[1]) * g[2] - 1e-3f, fz1 = ((__builtin_fmaxf(za, zb) + m2) - g[1]) * g[2] + 1e-3f;
-    if (!(fx0 <= fx1 && fz0 <= fz1)) return -1;                                         // (a NaN)
+    cannot1 = cannot1 || !(fx0 <= fx1 && fz0 <= fz1);                                   // (a NaN)
     if (seg) {
         const float Xa = (xa - g[0]) * g[2], Xb = (xb - g[0]) * g[2], Za = (za - g[1]) * g[2], Zb = (zb - g[1]) * g[2];
         seg->Xa = Xa; seg->Za = Za;
@@ -453,27 +453,34 @@ __device__ __forceinline__ int grid_cells(D3 o, D3 d, const float (&g)[8], int G
         seg->SL = __builtin_fabsf(Zb - Za) >= 1e-2f ? (Xb - Xa) * __builtin_amdgcn_rcpf(Zb - Za) : __builtin_nanf("");
         seg->m = (g[7] + 10.0f * e) * g[2] + 1e-3f;
     }
-    // (float -> int conversions saturate; the cells are clamped to the grid like the host clamps the centres)
+    // (float -> int conversions saturate, a NaN converts to 0; the cells are clamped to the grid like the host clamps the centres)
     ix0 = min(max((int)__builtin_floorf(fx0), 0), G - 1);
     iz0 = min(max((int)__builtin_floorf(fz0), 0), G - 1);
     nx = min(max((int)__builtin_floorf(fx1), 0), G - 1) - ix0 + 1;
     nz = min(max((int)__builtin_floorf(fz1), 0), G - 1) - iz0 + 1;
-    return nx * nz;
+    return cannot0 ? -1 : (empty ? 0 : (cannot1 ? -1 : nx * nz));          // (the order of the four early returns this replaces)
 }
 
+// the ray as the f32 filter and the footprint see it: six conversions and the 1-norm of the origin, once per bounce
+__device__ __forceinline__ void ray_f32(D3 o, D3 d, float (&of)[3], float (&df)[3], float &o1)
+{
+    of[0] = (float)o.x; of[1] = (float)o.y; of[2] = (float)o.z;
+    df[0] = (float)d.x; df[1] = (float)d.y; df[2] = (float)d.z;
+    o1 = (__builtin_fabsf(of[0]) + __builtin_fabsf(of[1])) + __builtin_fabsf(of[2]);
+}
 struct TubeRay {
     float u[2][3];      // lambda * u_k
     float t[2];         // -(lambda u_k) . o
     bool sane;          // false: outside the analysed range, every sphere must be tested exactly
 };
 
-__device__ __forceinline__ TubeRay make_tube(D3 o, D3 d, float rho)
+// (of, df: the ray's origin and direction rounded to f32; o1 = |of|_1 >= |of|: ray_f32() below)
+__device__ __forceinline__ TubeRay make_tube(const float (&of)[3], const float (&df)[3], float o1, float rho)
 {
     TubeRay T;
-    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
-    const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    const float ox = of[0], oy = of[1], oz = of[2];
+    const float dx = df[0], dy = df[1], dz = df[2];
     const float a = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-    const float o1 = (__builtin_fabsf(ox) + __builtin_fabsf(oy)) + __builtin_fabsf(oz);        // |o|_1 >= |o|
     const float s = __builtin_amdgcn_rsqf(a);
     const float gx = dx * s, gy = dy * s, gz = dz * s;
     // orthonormal basis without a branch or a singular direction (Duff et al., JCGT 2017)
@@ -496,6 +503,12 @@ __device__ __forceinline__ TubeRay make_tube(D3 o, D3 d, float rho)
         for (int k = 0; k < 2; ++k) { T.u[k][0] = T.u[k][1] = T.u[k][2] = 0.0f; T.t[k] = 3.0e38f; }
     }
     return T;
+}
+__device__ __forceinline__ TubeRay make_tube(D3 o, D3 d, float rho)
+{
+    float of[3], df[3], o1;
+    ray_f32(o, d, of, df, o1);
+    return make_tube(of, df, o1, rho);
 }
 // a lane without a ray: |h| is huge for every column
 __device__ __forceinline__ TubeRay no_tube_ray()

@@ -775,7 +775,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 const bool scan = alive;
                 const unsigned long long scan_mask = __ballot(scan);
                 if (scan_mask != 0ull) {
-                const TubeRay T = scan ? make_tube(o, d, P.tube_rho) : no_tube_ray();
+                float ray_of[3], ray_df[3], ray_o1;                 // (the ray in f32, shared by the filter rows and the footprint)
+                ray_f32(o, d, ray_of, ray_df, ray_o1);
+                const TubeRay T = scan ? make_tube(ray_of, ray_df, ray_o1, P.tube_rho) : no_tube_ray();
                 bf16x8 A[4];
                 {
                     uint32_t w[2][8];
@@ -875,7 +877,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     int ix0 = 0, nx = 0, iz0 = 0, nz = 0, cnt = 0;
                     GridSeg seg;
                     RT_STAMP(5);
-                    if (scan && T.sane) cnt = grid_cells(o, d, P.grid, P.grid_dim, P.scene_scale, ix0, nx, iz0, nz, SMALLGRID ? nullptr : &seg);
+                    if (scan && T.sane) cnt = grid_cells(ray_of, ray_df, ray_o1, P.grid, P.grid_dim, P.scene_scale, ix0, nx, iz0, nz, SMALLGRID ? nullptr : &seg);
                     RT_STAMP(7);
                     const int gcells = P.grid_dim * P.grid_dim;
                     if (SMALLGRID || P.n_global + gcells <= 64) {
