@@ -33,6 +33,11 @@ pub const RT_FLAG_NO_FILTER: u32 = 0x2;
 pub const RT_FLAG_DIAG_STATS: u32 = 0x4;
 pub const RT_FLAG_UNIFORM53: u32 = 0x8;
 
+/// The two limits of the boundary where the reference's own types are unbounded (include/rtiow_hip.h): the length of
+/// `HittableList` (src/shapes/mod.rs:52) and the pixel sum (src/main.rs:127,135: here exact u64 sums of samples clamped at 2^16).
+pub const RT_MAX_SPHERES: i32 = 1 << 24;
+pub const RT_SAMPLE_CLAMP: f64 = 65536.0;
+
 /// Opaque `rt_context`.
 #[repr(C)]
 pub struct rt_context {

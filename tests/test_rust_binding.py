@@ -61,6 +61,9 @@ def test_extern_block_declares_the_product_abi():
         assert re.search(r"pub const %s: i32 = %s;" % (k, v), RS), k
     for k, v in re.findall(r"#define (RT_FLAG_\w+)\s+(0x[0-9a-f]+)u", HDR):
         assert re.search(r"pub const %s: u32 = %s;" % (k, v), RS), k
+    # the two limits of the boundary
+    assert re.search(r"#define RT_MAX_SPHERES \(1 << 24\)", HDR) and "pub const RT_MAX_SPHERES: i32 = 1 << 24;" in RS
+    assert re.search(r"#define RT_SAMPLE_CLAMP 65536\.0", HDR) and "pub const RT_SAMPLE_CLAMP: f64 = 65536.0;" in RS
 
 
 def test_shim_covers_the_reference_types_with_private_fields():
