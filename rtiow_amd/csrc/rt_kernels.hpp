@@ -650,8 +650,15 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             unsigned int *pool_w = &s_pool[wave][0];
             unsigned long long *best_w = &s_best[wave * 64];
             unsigned int *bidx_w = &s_bidx[wave * 64];
-            best_w[lane] = 0xFFF0000000000000ull;                       // f64_key(+inf): closest = infinity
-            bidx_w[lane] = 0u;                                          // sphere index + 1; 0 = none
+            // The large-grid kernel seeds each ray's minimum with what the always-exact list (or the in-order scan of a ray
+            // outside the filter's range) has found, below: `closest` and `hit` then need no registers across the tile loop
+            // (1 spilled VGPR instead of 7, their reloads sat in the candidate-recording path; 10k-sphere scene -0.8 %.  The
+            // small-grid kernel has no spilled VGPR and measured 0.7 % SLOWER with the seed.)
+            constexpr bool SEED = TUBE && !SMALLGRID;
+            if constexpr (!SEED) {
+                best_w[lane] = 0xFFF0000000000000ull;                   // f64_key(+inf): closest = infinity
+                bidx_w[lane] = 0u;                                      // sphere index + 1; 0 = none
+            }
             uint32_t pool_n = 0, pool_done = 0;                         // wave-uniform
             auto pool_round = [&]() {
                 RT_STAMP(10);
@@ -761,6 +768,12 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 RT_STAMP(10);
                 while (pool_done < pool_n) pool_round();
                 const unsigned int hb = bidx_w[lane];
+                if constexpr (SEED) {
+                    // (the seeded minimum IS the closest hit: equal roots took the maximum of the list indices, seed included --
+                    //  mod.rs:61-67's later-sphere-wins; a ray outside the filter's range has no candidates, its seed, NaN roots
+                    //  included, comes back bit for bit)
+                    if (alive) { hit = (int)hb - 1; closest = key_f64(best_w[lane]); }
+                } else
                 if (alive && hb != 0u) {
                     const double root = key_f64(best_w[lane]);
                     const int idx = (int)hb - 1;
@@ -789,6 +802,10 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 if (scan && !T.sane) {
                     closest = __builtin_inf(); hit = -1;
                     for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i, std::true_type{}); }
+                }
+                if constexpr (SEED) {
+                    best_w[lane] = f64_key(closest);                    // (+inf without a hit: 0xFFF0000000000000)
+                    bidx_w[lane] = (unsigned)(hit + 1);                 // sphere index + 1; 0 = none
                 }
                 typedef float f32x16 __attribute__((ext_vector_type(16)));
                 const int ntt = nt >> 1;                    // tiles of 32 spheres; the tables hold ntt + 1
@@ -920,61 +937,57 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                         list_all = false;
                         n_list = P.n_global + __builtin_popcountll(cells);
                     } else if (!SMALLGRID && __ballot(cnt < 0) == 0ull) {
-                        // a large grid: one 64-bit word per grid ROW in LDS, ORed by the rays; lane l then owns row l,
-                        // a prefix sum over the rows' cell counts gives each row its place in the list
-#if RT_GROUP_SKIP
-                        // (one set of row words per 16-ray group, 2 KB of the bitmap area, free until the tile loop: each list entry
-                        //  then carries in its top four bits which groups can reach the tile)
-                        unsigned long long *tm = reinterpret_cast<unsigned long long *>(bits_w);   // [4][64]
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) tm[g * 64 + lane] = 0ull;
-                        unsigned long long *tm_g = tm + (lane >> 4) * 64;
-#else
-                        unsigned long long *tm = reinterpret_cast<unsigned long long *>(bits_w);   // (512 B of the bitmap area, free until the tile loop)
-                        tm[lane] = 0ull;
-                        unsigned long long *tm_g = tm;
-#endif
-                        __builtin_amdgcn_wave_barrier();
-                        // row by row: the columns of the part of the clipped piece that lies in the row's band (grid_row_run)
+                        // a large grid: one word per grid ROW in LDS (32 bits for grids of at most 32 cells per side -- the 10k-sphere
+                        // scene's 19 x 19 --, else 64: shifts, counts and bit scans of a 64-bit word are two or three instructions each),
+                        // ORed by the rays; lane l then owns row l, a prefix sum over the rows' cell counts gives each row its place in
+                        // the list.  One set of row words per 16-ray group (at most 2 KB of the bitmap area, free until the tile loop):
+                        // each list entry carries in its top four bits which groups can reach the tile.
                         if (cnt == 0) nz = 0;
-                        for (int k = 0; __any(k < nz); ++k)
-                            if (k < nz) {
-                                int rx0, rnx;                                               // rnx + rx0 <= grid_dim <= 63
-                                grid_row_run(seg, P.grid_dim, iz0 + k, rx0, rnx);
-                                atomicOr(&tm_g[iz0 + k], ((1ull << rnx) - 1ull) << rx0);
-                            }
-                        __builtin_amdgcn_wave_barrier();
-#if RT_GROUP_SKIP
-                        const unsigned long long w0 = tm[lane], w1 = tm[64 + lane], w2 = tm[128 + lane], w3 = tm[192 + lane];
-                        unsigned long long mw = (w0 | w1) | (w2 | w3);
-#else
-                        unsigned long long mw = tm[lane];
-#endif
-                        const int mine = __builtin_popcountll(mw);
-                        const int upto = wave_scan_add(mine);
-                        const int tn = P.n_global + __builtin_amdgcn_readlane(upto, 63);
-                        if (tn <= kListCap) {
-                            if (lane < P.n_global) tl[lane] = (unsigned)lane | (RT_GROUP_SKIP ? 0xF0000000u : 0u);
-                            int pos = P.n_global + upto - mine;
-                            const int row0 = P.n_global + lane * P.grid_dim;
-                            while (__any(mw != 0ull)) {
-                                if (mw != 0ull) {
-                                    const int b = __builtin_ctzll(mw);
-#if RT_GROUP_SKIP
-                                    const unsigned gm = (unsigned)((w0 >> b) & 1ull) | (unsigned)((w1 >> b) & 1ull) << 1 |
-                                                        (unsigned)((w2 >> b) & 1ull) << 2 | (unsigned)((w3 >> b) & 1ull) << 3;
-                                    tl[pos++] = (unsigned)(row0 + b) | (gm << 28);
-#else
-                                    tl[pos++] = (unsigned)(row0 + b);
-#endif
-                                    mw &= mw - 1ull;
-                                }
-                            }
-                            if (lane < 2) tl[tn + lane] = (unsigned)ntt | (RT_GROUP_SKIP ? 0xF0000000u : 0u);
+                        auto build_list = [&](auto zero) {
+                            typedef decltype(zero) W;
+                            constexpr int kGroups = RT_GROUP_SKIP ? 4 : 1;
+                            W *tm = reinterpret_cast<W *>(bits_w);                          // [kGroups][64]
+#pragma unroll
+                            for (int g = 0; g < kGroups; ++g) tm[g * 64 + lane] = (W)0;
+                            W *tm_g = tm + (RT_GROUP_SKIP ? (lane >> 4) * 64 : 0);
                             __builtin_amdgcn_wave_barrier();
-                            list_all = false;
-                            n_list = tn;
-                        }
+                            // row by row: the columns of the part of the clipped piece that lies in the row's band (grid_row_run)
+                            for (int k = 0; __any(k < nz); ++k)
+                                if (k < nz) {
+                                    int rx0, rnx;                                           // 1 <= rnx, rnx + rx0 <= grid_dim <= 32 or 63
+                                    grid_row_run(seg, P.grid_dim, iz0 + k, rx0, rnx);
+                                    atomicOr(&tm_g[iz0 + k], (W)((W)(~(W)0 >> (8 * (int)sizeof(W) - rnx)) << rx0));
+                                }
+                            __builtin_amdgcn_wave_barrier();
+                            W wg[kGroups];
+                            W mw = (W)0;
+#pragma unroll
+                            for (int g = 0; g < kGroups; ++g) { wg[g] = tm[g * 64 + lane]; mw |= wg[g]; }
+                            const int mine = sizeof(W) == 8 ? __builtin_popcountll(mw) : __builtin_popcount((unsigned)mw);
+                            const int upto = wave_scan_add(mine);
+                            const int tn = P.n_global + __builtin_amdgcn_readlane(upto, 63);
+                            if (tn <= kListCap) {
+                                const unsigned kAll = RT_GROUP_SKIP ? 0xF0000000u : 0u;
+                                if (lane < P.n_global) tl[lane] = (unsigned)lane | kAll;
+                                int pos = P.n_global + upto - mine;
+                                const int row0 = P.n_global + lane * P.grid_dim;
+                                while (__any(mw != (W)0)) {
+                                    if (mw != (W)0) {
+                                        const int bpos = sizeof(W) == 8 ? __builtin_ctzll(mw) : __builtin_ctz((unsigned)mw);
+                                        unsigned gm = 0u;
+#pragma unroll
+                                        for (int g = 0; g < (RT_GROUP_SKIP ? 4 : 0); ++g) gm |= (unsigned)((wg[g] >> bpos) & (W)1) << g;
+                                        tl[pos++] = (unsigned)(row0 + bpos) | (gm << 28);
+                                        mw &= mw - (W)1;
+                                    }
+                                }
+                                if (lane < 2) tl[tn + lane] = (unsigned)ntt | kAll;
+                                __builtin_amdgcn_wave_barrier();
+                                list_all = false;
+                                n_list = tn;
+                            }
+                        };
+                        if (P.grid_dim <= 32) build_list(0u); else build_list(0ull);
                     }
                 }
                 RT_STAMP(3);
