@@ -131,10 +131,11 @@ def rmse_vs_cpu(gpu_fix_rows, gpu_rgba_rows_bottom_up, cpu_sums, spp):
 
 
 def kernel_name(scan_mode, kernel_variant):
-    """The instantiation rt_stats names, spelled as rocprofv3's kernel trace spells it: render_kernel<MODE, DIAG, SMALLGRID, U53>
-    (rt_stats.kernel_variant: bit 0 = the small-grid kernel, bit 1 = 53-bit uniforms; bench.py never sets RT_FLAG_DIAG_STATS)."""
+    """The instantiation rt_stats names, spelled as rocprofv3's kernel trace spells it: render_kernel<MODE, DIAG, SMALLGRID, U53, ITEMS>
+    (rt_stats.kernel_variant: bit 0 = the small-grid kernel, bit 1 = 53-bit uniforms, bit 2 = work blocks of 1 024 pixel-samples instead
+    of 256; bench.py never sets RT_FLAG_DIAG_STATS)."""
     b = lambda x: "true" if x else "false"
-    return f"rt::render_kernel<{int(scan_mode)}, false, {b(kernel_variant & 1)}, {b(kernel_variant & 2)}>"
+    return f"rt::render_kernel<{int(scan_mode)}, false, {b(kernel_variant & 1)}, {b(kernel_variant & 2)}, {1024 if kernel_variant & 4 else 256}>"
 
 
 def launch_command(n_ranks, port, argv):

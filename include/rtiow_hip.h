@@ -127,7 +127,8 @@ typedef struct {
                                     1 VALU cross-check (RTIOW_SCAN_MODE=1); 2-4 only in RTIOW_CROSSCHECK_MODES builds */
     int32_t  kernel_variant;     /* which instantiation of the kernel ran, as bits: 1 the scan_mode-5 kernel for scenes whose
                                     tile grid has <= 64 cells (else the general one, and every other scan mode); 2 the
-                                    RT_FLAG_UNIFORM53 instantiation */
+                                    RT_FLAG_UNIFORM53 instantiation; 4 work blocks of 1 024 pixel-samples instead of 256 (launches of
+                                    >= 2^28 pixel-samples at >= 147 samples per pixel) */
     uint64_t live_per_bounce[64]; /* rays traced at bounce index k (0 = camera ray; indices >= 63 share the
                                     last slot); sums to rays_traced (RT_FLAG_DIAG_STATS, else 0) */
     uint64_t direct_samples;     /* samples added to the frame buffer one by one instead of through their block's

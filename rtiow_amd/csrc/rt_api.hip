@@ -298,13 +298,13 @@ int upload_table(T **dst, const T *src, size_t count)
     return RT_OK;
 }
 
-template <int MODE, bool DIAG, bool SMALLGRID = false, bool U53 = false>
+template <int MODE, bool DIAG, bool SMALLGRID = false, bool U53 = false, int ITEMS = rt::kItemBlock>
 int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, int *grid_out)
 {
     int per_cu = ctx->blocks_per_cu;
     if (per_cu <= 0) {
         int occ = 0;
-        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rt::render_kernel<MODE, DIAG, SMALLGRID, U53>, rt::kBlock, 0));
+        RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rt::render_kernel<MODE, DIAG, SMALLGRID, U53, ITEMS>, rt::kBlock, 0));
         per_cu = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
     }
     // persistent grid, but never more lanes than there are work items
@@ -314,7 +314,7 @@ int launch_render(rt_context *ctx, const rt::KParams &kp, hipStream_t stream, in
     if (grid < 1) grid = 1;
     *grid_out = (int)grid;
     RT_HIP(hipEventRecord(ctx->ev0, stream));
-    hipLaunchKernelGGL((rt::render_kernel<MODE, DIAG, SMALLGRID, U53>), dim3((unsigned)grid), dim3(rt::kBlock), 0, stream, kp);
+    hipLaunchKernelGGL((rt::render_kernel<MODE, DIAG, SMALLGRID, U53, ITEMS>), dim3((unsigned)grid), dim3(rt::kBlock), 0, stream, kp);
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(ctx->ev1, stream));
     return RT_OK;
@@ -727,7 +727,16 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     // Work items are single pixel-samples in pixel-major order (item w = pixel * spp + sample), handed out in
     // blocks of kItemBlock consecutive items; the work counter counts blocks.
     const unsigned long long total_items = (unsigned long long)npix * (unsigned long long)p->spp;
-    const unsigned long long n_blocks = (total_items + rt::kItemBlock - 1) / rt::kItemBlock;
+    // Blocks of kItemBlockLarge for launches that are long enough for their last blocks not to matter (rt_kernels.hpp): the shipped
+    // scan mode without the diagnostic counters, block sums in LDS, >= 147 samples per pixel, >= 2^28 pixel-samples.  RTIOW_LARGE_BLOCK_MIN_ITEMS
+    // moves the last threshold (tests: 0 = every launch that qualifies otherwise; a huge value = never).
+    const int mode_now = (p->flags & RT_FLAG_NO_FILTER) ? 0 : ctx->scan_mode;
+    const char *lb_env = getenv("RTIOW_LARGE_BLOCK_MIN_ITEMS");
+    const unsigned long long lb_min = (lb_env && *lb_env) ? strtoull(lb_env, nullptr, 0) : rt::kLargeMinItems;
+    const bool large_blocks = mode_now == 5 && !(p->flags & RT_FLAG_DIAG_STATS) && p->spp >= ctx->ring_min_spp &&
+                              p->spp >= rt::kLargeMinSpp && total_items >= lb_min;
+    const unsigned item_block = large_blocks ? rt::kItemBlockLarge : rt::kItemBlock;
+    const unsigned long long n_blocks = (total_items + item_block - 1) / item_block;
     if (n_blocks > 0x7fffffffULL)
         return fail(RT_ERR_INVALID_ARGUMENT, "rows*width*spp = %llu pixel-samples in one launch: at most 2^31 blocks of %d "
                     "(split the samples over several launches with sample_begin and RT_FLAG_ACCUMULATE)", total_items, rt::kItemBlock);
@@ -800,10 +809,12 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
         if (diag || (mode != 0 && mode != 5))
             return fail(RT_ERR_INVALID_ARGUMENT, "RT_FLAG_UNIFORM53 runs with scan mode 5 (the default) or RT_FLAG_NO_FILTER, without RT_FLAG_DIAG_STATS");
         if (mode == 0) rc = launch_render<0, false, false, true>(ctx, kp, stream, &grid);
-        else if (small_grid) rc = launch_render<5, false, true, true>(ctx, kp, stream, &grid);
-        else rc = launch_render<5, false, false, true>(ctx, kp, stream, &grid);
+        else if (small_grid) rc = large_blocks ? launch_render<5, false, true, true, rt::kItemBlockLarge>(ctx, kp, stream, &grid)
+                                              : launch_render<5, false, true, true>(ctx, kp, stream, &grid);
+        else rc = large_blocks ? launch_render<5, false, false, true, rt::kItemBlockLarge>(ctx, kp, stream, &grid)
+                               : launch_render<5, false, false, true>(ctx, kp, stream, &grid);
         if (rc) return rc;
-        ctx->last.kernel_variant = 2 | ((mode == 5 && small_grid) ? 1 : 0);
+        ctx->last.kernel_variant = 2 | ((mode == 5 && small_grid) ? 1 : 0) | (mode == 5 && large_blocks ? 4 : 0);
         ctx->launched = true;
         ctx->last.grid_blocks = grid;
         return RT_OK;
@@ -823,9 +834,12 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
 #endif
     case 10:        // (the shipped kernel has a leaner instantiation for scenes whose tile grid has <= 64 cells)
         if (small_grid) {
-            rc = launch_render<5, false, true>(ctx, kp, stream, &grid);
+            rc = large_blocks ? launch_render<5, false, true, false, rt::kItemBlockLarge>(ctx, kp, stream, &grid)
+                              : launch_render<5, false, true>(ctx, kp, stream, &grid);
             ctx->last.kernel_variant = 1;
-        } else rc = launch_render<5, false>(ctx, kp, stream, &grid);
+        } else rc = large_blocks ? launch_render<5, false, false, false, rt::kItemBlockLarge>(ctx, kp, stream, &grid)
+                                 : launch_render<5, false>(ctx, kp, stream, &grid);
+        if (large_blocks) ctx->last.kernel_variant |= 4;
         break;
     default: rc = launch_render<5, true>(ctx, kp, stream, &grid); break;
     }

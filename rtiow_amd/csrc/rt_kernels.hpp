@@ -55,7 +55,7 @@ struct KParams {
     int32_t n_spheres;
     int32_t use_ring;          // 1: per-wave LDS block sums (spp >= kRingMinSpp); 0: every sample goes to the frame buffer directly
     uint32_t npix;             // rows * width
-    uint32_t n_blocks;         // work blocks of kItemBlock consecutive pixel-samples, pixel-major: item w = pixel * spp + sample
+    uint32_t n_blocks;         // work blocks of ITEMS consecutive pixel-samples, pixel-major: item w = pixel * spp + sample
     unsigned long long total_items;   // npix * spp
     double inv_spp;            // 1.0 / spp (block -> first pixel)
     double inv_width;          // 1.0 / width (first pixel -> row, column)
@@ -97,6 +97,13 @@ constexpr int kBlock = 256;
 constexpr int kCandCap = 24;        // MODE 1: per-lane candidate slots
 constexpr int kScanUnroll = 8;      // MODE 1: spheres per scalar-load batch / overflow check
 constexpr int kItemBlock = 256;     // pixel-samples a wave reserves per atomic on the work counter
+// ... and 1 024 for launches of at least 2^28 pixel-samples at >= 147 samples per pixel (ceil(1023 / 147) + 1 = 8 pixels: still kRingSlots):
+// reserving a block is a returning atomic the whole wave waits for, and a block's sums are one frame-buffer request per pixel and channel:
+// a quarter of both (1200x675x500: 52.7 -> 51.3 ms; 10k spheres 1920x1080x256: 93.7 -> 91.5 ms).  Smaller launches keep 256: their last
+// blocks are the end-of-launch tail (1200x675x147 is 5 % slower with 1 024).
+constexpr int kItemBlockLarge = 1024;
+constexpr int kLargeMinSpp = 147;
+constexpr unsigned long long kLargeMinItems = 1ull << 28;
 constexpr int kRingSlots = 8;       // pixels a block may touch when its sums are kept in LDS: ceil(255 / spp) + 1 <= 8
 constexpr int kRingMinSpp = 37;     //   ... which holds from 37 spp per launch on; below that samples go to the frame buffer one by one
 constexpr int kRingDepth = 4;       // blocks of one wave that may be unfinished at the same time (older ones: see `orphan`)
@@ -186,7 +193,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // U53 (RT_FLAG_UNIFORM53): every uniform takes two consecutive Philox words (53 random bits, as rand's gen::<f64>()) instead
 // of one word's 24 bits: same draw order, same runs; the rejection tests run in f64 as the reference writes them (the
 // integer form needs the 2^-23 lattice).  An optional mode: ~2x the Philox work of the retry loops.
-template <int MODE, bool DIAG, bool SMALLGRID = false, bool U53 = false>
+// ITEMS: pixel-samples per work block (kItemBlock, or kItemBlockLarge for launches with enough samples: see rt_api.hip).
+template <int MODE, bool DIAG, bool SMALLGRID = false, bool U53 = false, int ITEMS = 256>
 // second launch bound = waves per SIMD the register allocator must leave room for: the bounce loop
 // is latency-bound, and the 4th wave is worth more than the few cold values it spills.  Only the shipped kernel
 // (MODE 5 without the diagnostic counters) fits four workgroups' LDS on a CU (40 000 of 40 960 bytes each); the
@@ -363,9 +371,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                         break;
                     }
                     // first item of the block -> (pixel, sample): W0 / spp in f64 (W0 < 2^39: exact), one correction step
-                    const unsigned long long W0 = (unsigned long long)nb * (unsigned long long)kItemBlock;
+                    const unsigned long long W0 = (unsigned long long)nb * (unsigned long long)ITEMS;
                     const unsigned long long left = P.total_items - W0;
-                    const uint32_t n_items = left < (unsigned long long)kItemBlock ? (uint32_t)left : (uint32_t)kItemBlock;
+                    const uint32_t n_items = left < (unsigned long long)ITEMS ? (uint32_t)left : (uint32_t)ITEMS;
                     uint32_t p0 = (uint32_t)((double)W0 * P.inv_spp);
                     long long rem = (long long)(W0 - (unsigned long long)p0 * (unsigned long long)(uint32_t)P.spp);
                     if (rem < 0) { p0 -= 1u; rem += (long long)P.spp; }

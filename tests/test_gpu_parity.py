@@ -7,6 +7,7 @@ Oracle B's on the same inputs, and the RGBA8 bytes must equal Oracle A's.
 The north_star's stated tolerance (per-pixel RMSE < 1e-4 vs CPU) is asserted
 against the literal Oracle A as well.
 """
+import os
 import numpy as np
 import pytest
 
@@ -405,3 +406,34 @@ def test_rays_and_scenes_outside_the_filters_analysed_range(renderer, oracle_mod
     fb, sb, stb = oracle_mod.render_b(oracle_mod.camera_from_host(cam), flat, oracle_mod.make_params(w, h, spp, t_min=t_min))
     assert np.array_equal(fix, fb)
     assert st["rays_traced"] == stb["rays_traced"] and st["rays_traced"] > 1.5 * w * h * spp     # (the scene is hit)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,w,h,spp,flags", [("book", 160, 90, 150, 0), ("book", 96, 54, 300, rt.RT_FLAG_UNIFORM53),
+                                                  ("3000", 120, 68, 147, 0), ("book", 131, 57, 211, 0)])
+def test_large_work_blocks_bit_exact(oracle_mod, book1_flat, scene, w, h, spp, flags):
+    """Launches of >= 2^28 pixel-samples at >= 147 samples per pixel hand out work in blocks of 1 024 pixel-samples instead of
+    256 (another instantiation of the kernel: rt_stats.kernel_variant bit 2).  RTIOW_LARGE_BLOCK_MIN_ITEMS=0 selects it for a
+    launch small enough for the oracle: both grid variants, the 53-bit stream, ragged sizes (a last block that is not full,
+    blocks that straddle rows), and a second pass with sample_begin -- against Oracle B, bit for bit."""
+    flat = book1_flat if scene == "book" else rt.random_scene(3, grid=(-27, 27)).flatten()
+    os.environ["RTIOW_LARGE_BLOCK_MIN_ITEMS"] = "0"
+    try:
+        with rt.Renderer(0) as r:
+            r.upload_scene(flat)
+            cam = rt.book1_camera(w, h)
+            _, fix, st = r.render(cam, rt.make_params(w, h, spp, flags=flags))
+            assert st["kernel_variant"] & 4 and st["direct_samples"] < st["samples"] // 100
+            ocam = oracle_mod.camera_from_host(cam)
+            fb, _, stb = oracle_mod.render_b(ocam, flat, oracle_mod.make_params(w, h, spp, uniform53=bool(flags & rt.RT_FLAG_UNIFORM53), nthreads=8))
+            assert np.array_equal(fix, fb) and st["rays_traced"] == stb["rays_traced"]
+            _, fix2, st2 = r.render(cam, rt.make_params(w, h, 150, sample_begin=1000, flags=flags))
+            fb2, _, _ = oracle_mod.render_b(ocam, flat, oracle_mod.make_params(w, h, 150, sample_begin=1000, uniform53=bool(flags & rt.RT_FLAG_UNIFORM53), nthreads=8))
+            assert st2["kernel_variant"] & 4 and np.array_equal(fix2, fb2)
+        os.environ["RTIOW_LARGE_BLOCK_MIN_ITEMS"] = str(1 << 62)          # never: the same launch on blocks of 256 gives the same frame
+        with rt.Renderer(0) as r:
+            r.upload_scene(flat)
+            _, fix3, st3 = r.render(rt.book1_camera(w, h), rt.make_params(w, h, spp, flags=flags))
+            assert not (st3["kernel_variant"] & 4) and np.array_equal(fix3, fb)
+    finally:
+        os.environ.pop("RTIOW_LARGE_BLOCK_MIN_ITEMS")

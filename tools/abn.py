@@ -8,7 +8,7 @@ from rtiow_amd import _ffi
 import rtiow_amd as rt
 flat = np.ascontiguousarray(rt.random_scene(1).flatten(), dtype=rt.SPHERE_DTYPE)
 cam = rt.book1_camera(1200, 675).to_rt_camera()
-p = rt.make_params(1200, 675, 100)
+p = rt.make_params(1200, 675, int(os.environ.get("SPP", "100")))
 libs = []
 for path in sys.argv[1:]:
     lib = C.CDLL(os.path.abspath(path))
