@@ -1340,9 +1340,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     ev += nblk;
                     sp = mk(sx, sy, sz);
                   } else {
-                    const double2 mD = *reinterpret_cast<const double2 *>(mrec + 6);  // 1/ir, r0(1/ir)
-                    const double2 mE = *reinterpret_cast<const double2 *>(mrec + 8);  // r0(ir), -
-                    inv_param = mD.x; r0_front = mD.y; r0_back = mE.x;
+                    inv_param = mD_.x; r0_front = mD_.y; r0_back = mE_.x;
                   }
                 } else
                 if (kind != RT_KIND_DIALECTRIC) {
