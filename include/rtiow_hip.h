@@ -136,6 +136,16 @@ typedef struct {
                                     that a path of more than ~30 bounces held open for too long */
 } rt_stats;
 
+/* ---- diagnostic knobs (environment; none changes a result) -------------------
+ * Read by the library, for tests and measurements only -- every one of them selects another way of computing the
+ * SAME frame (the parity tests run the knobs against the oracle):
+ *   RTIOW_SCAN_MODE=1|5            rt_create: the sphere-scan filter (5 tube filter on the matrix pipe, shipped; 1 VALU cross-check)
+ *   RTIOW_NO_GRID=1, RTIOW_GRID_DIM=G   rt_upload_scene: no tile grid / G x G cells instead of the cost model's choice
+ *   RTIOW_BLOCKS_PER_CU=k          rt_create: workgroups per CU of the persistent grid (default: the occupancy query)
+ *   RTIOW_RING_MIN_SPP=n           rt_create: per-block pixel sums in LDS from n samples per pixel on (default and minimum 37)
+ *   RTIOW_LARGE_BLOCK_MIN_ITEMS=n  per launch: work blocks of 1 024 pixel-samples instead of 256 from n pixel-samples per launch on
+ *                                  (default 2^28; also needs >= 147 samples per pixel; rt_stats.kernel_variant bit 2 says which ran) */
+
 /* ---- lifetime -------------------------------------------------------------- */
 
 /* Opens HIP device `device_id`.  Fails with RT_ERR_NO_DEVICE when there is no
