@@ -398,23 +398,29 @@ constexpr float kTubeOriginErr = 128.0f * kUnitRoundoff;
 // piece whose z lies in that row's band.  Margins: the f32 end points lie within 4 e of the true ones, so every point of
 // the true piece is within 6 e of the computed segment (as point sets -- no amplification by the slope); the band and the
 // run are grown by pad + 10 e (in cells) + 1e-3 cells, the run by 1e-2 cells more for the slope's own rounding; a piece
-// whose z extent is below 1e-2 cells (the slope would be ill-conditioned) or whose evaluation is not finite takes the
-// rectangle's whole run; a run never leaves the rectangle.
+// whose z extent is below 1e-2 cells (the slope would be ill-conditioned) or whose slope is not finite takes the
+// rectangle's whole run; a run never leaves the rectangle's columns (it is clamped to them as cells).  The band's ends
+// are clipped to the piece BEFORE x is evaluated (the differences from end a stay below the piece's own extent: a steep
+// slope multiplies no cancellation error), and their rounding (<= 8e-6 cells) is inside the band's 1e-3.
 struct GridSeg {
-    float Xa, Za, SL;           // x = Xa + (z - Za) * SL on the piece (cells)
-    float Xlo, Xhi, Zlo, Zhi;   // its bounding rectangle (cells, no margin)
-    float m;                    // (pad + 10 e) / cell + 1e-3
+    // The piece in the coordinate zeta = sg * z (sg = the sign of the slope dx/dz, so that x INCREASES with zeta), relative to
+    // end a: x = Xa + (zeta - zeta_a) * |SL|.  Everything a row needs is folded into eight per-ray constants, so one row is
+    // two fma for the band's ends, one max and one min to clip them to the piece, two fma for x (15 vector instructions with
+    // the conversions and clamps; the form with z clipped first, both end points evaluated and sorted, and the rectangle
+    // clipped afterwards took 32):
+    float sg;                   // +1 or -1
+    float alo, ahi;             // band of row iz in zeta, relative to end a: [sg * iz + alo, sg * iz + ahi]  (margin m inside)
+    float dmin, dmax;           // the piece's zeta range relative to end a (one of them is 0)
+    float sl;                   // |SL|; 0 for a piece that takes the rectangle's whole run
+    float xl, xh;               // Xa -+ (1e-2 + m); a whole-run piece: Xlo - m, Xhi + m
 };
-__device__ __forceinline__ void grid_row_run(const GridSeg &s, int G, int iz, int &ix0, int &nx)
+// (c0 .. c1: the rectangle's columns, grid_cells' ix0 .. ix0 + nx - 1; fz: the row as a float)
+__device__ __forceinline__ void grid_row_run(const GridSeg &s, int c0, int c1, float fz, int &ix0, int &nx)
 {
-    const float zl = __builtin_fmaxf(s.Zlo, (float)iz - s.m), zh = __builtin_fminf(s.Zhi, (float)(iz + 1) + s.m);
-    const float xl = __builtin_fmaf(zl - s.Za, s.SL, s.Xa), xh = __builtin_fmaf(zh - s.Za, s.SL, s.Xa);
-    const bool whole = !(__builtin_fabsf(xl) < 1e30f && __builtin_fabsf(xh) < 1e30f);      // (a flat piece has SL = NaN)
-    float lo = whole ? s.Xlo : __builtin_fmaxf(__builtin_fminf(xl, xh) - 1e-2f, s.Xlo);
-    float hi = whole ? s.Xhi : __builtin_fminf(__builtin_fmaxf(xl, xh) + 1e-2f, s.Xhi);
-    lo -= s.m; hi += s.m;
-    ix0 = min(max((int)__builtin_floorf(lo), 0), G - 1);
-    nx = min(max((int)__builtin_floorf(hi), 0), G - 1) - ix0 + 1;
+    const float dl = __builtin_fmaxf(__builtin_fmaf(s.sg, fz, s.alo), s.dmin), dh = __builtin_fminf(__builtin_fmaf(s.sg, fz, s.ahi), s.dmax);
+    const float lo = __builtin_fmaf(dl, s.sl, s.xl), hi = __builtin_fmaf(dh, s.sl, s.xh);
+    ix0 = min(max((int)__builtin_floorf(lo), c0), c1);
+    nx = min(max((int)__builtin_floorf(hi), c0), c1) - ix0 + 1;
 }
 
 // (of, df: the ray's origin and direction rounded to f32, o1 = |of|_1 -- shared with make_tube)
@@ -447,11 +453,19 @@ __device__ __forceinline__ int grid_cells(const float (&of)[3], const float (&df
     cannot1 = cannot1 || !(fx0 <= fx1 && fz0 <= fz1);                                   // (a NaN)
     if (seg) {
         const float Xa = (xa - g[0]) * g[2], Xb = (xb - g[0]) * g[2], Za = (za - g[1]) * g[2], Zb = (zb - g[1]) * g[2];
-        seg->Xa = Xa; seg->Za = Za;
-        seg->Xlo = __builtin_fminf(Xa, Xb); seg->Xhi = __builtin_fmaxf(Xa, Xb);
-        seg->Zlo = __builtin_fminf(Za, Zb); seg->Zhi = __builtin_fmaxf(Za, Zb);
-        seg->SL = __builtin_fabsf(Zb - Za) >= 1e-2f ? (Xb - Xa) * __builtin_amdgcn_rcpf(Zb - Za) : __builtin_nanf("");
-        seg->m = (g[7] + 10.0f * e) * g[2] + 1e-3f;
+        const float m = (g[7] + 10.0f * e) * g[2] + 1e-3f;
+        const float dz = Zb - Za, SL = (Xb - Xa) * __builtin_amdgcn_rcpf(dz);
+        const bool whole = !(__builtin_fabsf(dz) >= 1e-2f && __builtin_fabsf(SL) < 1e6f);     // (too flat for a slope, or not finite)
+        const bool neg = !whole && SL < 0.0f;
+        const float za_ = neg ? -Za : Za, zb_ = neg ? -Zb : Zb;                                 // zeta of the two ends
+        seg->sg = neg ? -1.0f : 1.0f;
+        seg->alo = (neg ? -(1.0f + m) : -m) - za_;
+        seg->ahi = (neg ? m : 1.0f + m) - za_;
+        seg->dmin = __builtin_fminf(zb_ - za_, 0.0f);
+        seg->dmax = __builtin_fmaxf(zb_ - za_, 0.0f);
+        seg->sl = whole ? 0.0f : __builtin_fabsf(SL);
+        seg->xl = (whole ? __builtin_fminf(Xa, Xb) : Xa - 1e-2f) - m;
+        seg->xh = (whole ? __builtin_fmaxf(Xa, Xb) : Xa + 1e-2f) + m;
     }
     // (float -> int conversions saturate, a NaN converts to 0; the cells are clamped to the grid like the host clamps the centres)
     ix0 = min(max((int)__builtin_floorf(fx0), 0), G - 1);

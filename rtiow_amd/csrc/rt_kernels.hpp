@@ -398,7 +398,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     }
                 }
                 const uint32_t n_gen = min(64u, blk_end - blk_next);
+#ifndef RT_COUNT_ROWS
                 RT_COUNT(1);
+#endif
                 if ((uint32_t)lane < n_gen) {
                     // item blk_next + lane of the block: sample blk_s0 + that of pixel blk_pix0, carried over into the next pixels
                     const uint32_t s_rel = blk_s0 + blk_next + (uint32_t)lane;
@@ -970,12 +972,16 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                             W *tm_g = tm + (RT_GROUP_SKIP ? (lane >> 4) * 64 : 0);
                             __builtin_amdgcn_wave_barrier();
                             // row by row: the columns of the part of the clipped piece that lies in the row's band (grid_row_run)
-                            for (int k = 0; __any(k < nz); ++k)
+                            for (int k = 0; __any(k < nz); ++k) {
+#ifdef RT_COUNT_ROWS
+                                RT_COUNT(1);
+#endif
                                 if (k < nz) {
                                     int rx0, rnx;                                           // 1 <= rnx, rnx + rx0 <= grid_dim <= 32 or 63
-                                    grid_row_run(seg, P.grid_dim, iz0 + k, rx0, rnx);
+                                    grid_row_run(seg, ix0, ix0 + nx - 1, (float)(iz0 + k), rx0, rnx);
                                     atomicOr(&tm_g[iz0 + k], (W)((W)(~(W)0 >> (8 * (int)sizeof(W) - rnx)) << rx0));
                                 }
+                            }
                             __builtin_amdgcn_wave_barrier();
                             W wg[kGroups];
                             W mw = (W)0;
@@ -990,6 +996,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                                 int pos = P.n_global + upto - mine;
                                 const int row0 = P.n_global + lane * P.grid_dim;
                                 while (__any(mw != (W)0)) {
+#ifdef RT_COUNT_ROWS
+                                    RT_COUNT(6);
+#endif
                                     if (mw != (W)0) {
                                         const int bpos = sizeof(W) == 8 ? __builtin_ctzll(mw) : __builtin_ctz((unsigned)mw);
                                         unsigned gm = 0u;
@@ -1323,7 +1332,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     double sx = u11_53(w.x, w.y), sy = u11_53(w.z, w.w), sz = u11_53(b1.x, b1.y);
                     bool ok = sx * sx + sy * sy + sz * sz < 1.0;
                     while (!ok) {
+#ifndef RT_COUNT_ROWS
                         RT_COUNT(6);
+#endif
                         U4 b = philox4x32_10(pix_global, (uint32_t)s, ev + nblk, 0u, P.k0, P.k1);
                         nblk++;
                         sx = u11_53(c0, c1); sy = u11_53(b.x, b.y); sz = u11_53(b.z, b.w);       // try 2m+1: ends its block
@@ -1353,7 +1364,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     if (!ok) {
                         uint32_t c0 = w.w;                                       // the word left over from the block before
                         do {
+#ifndef RT_COUNT_ROWS
                             RT_COUNT(6);
+#endif
                             U4 b = philox4x32_10(pix_global, (uint32_t)s, ev + nblk, 0u, P.k0, P.k1);
                             nblk++;
                             tx = c0; ty = b.x; tz = b.y;                         // try 4m+1

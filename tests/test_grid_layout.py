@@ -137,18 +137,26 @@ def model_grid_cells(o, d, g, G, scale, rng, shrink=0.25):
         # the footprint row by row (GridSeg / grid_row_run: grids of more than 64 cells): columns of every grid row
         Xa, Xb = ((xa - g[0]) * g[2]).astype(f32), ((xb - g[0]) * g[2]).astype(f32)
         Za, Zb = ((za - g[1]) * g[2]).astype(f32), ((zb - g[1]) * g[2]).astype(f32)
-        Xlo, Xhi, Zlo, Zhi = np.minimum(Xa, Xb), np.maximum(Xa, Xb), np.minimum(Za, Zb), np.maximum(Za, Zb)
-        SL = np.where(np.abs(Zb - Za) >= f32(1e-2), (Xb - Xa) * ulp_jitter((f32(1.0) / (Zb - Za).astype(np.float64)).astype(f32), rng), f32(np.nan)).astype(f32)
         m = ((g[7] + f32(10.0) * e) * g[2] + f32(1e-3 * shrink)).astype(f32)
+        dz = (Zb - Za).astype(f32)
+        SL = ((Xb - Xa) * ulp_jitter((f32(1.0) / dz.astype(np.float64)).astype(f32), rng)).astype(f32)
+        whole = ~((np.abs(dz) >= f32(1e-2)) & (np.abs(SL) < f32(1e6)))
+        neg = ~whole & (SL < 0)
+        za_, zb_ = np.where(neg, -Za, Za).astype(f32), np.where(neg, -Zb, Zb).astype(f32)
+        sg = np.where(neg, f32(-1.0), f32(1.0)).astype(f32)
+        alo = (np.where(neg, -(f32(1.0) + m), -m).astype(f32) - za_).astype(f32)
+        ahi = (np.where(neg, m, f32(1.0) + m).astype(f32) - za_).astype(f32)
+        dmin, dmax = np.minimum((zb_ - za_).astype(f32), f32(0.0)), np.maximum((zb_ - za_).astype(f32), f32(0.0))
+        sl = np.where(whole, f32(0.0), np.abs(SL)).astype(f32)
+        xl = (np.where(whole, np.minimum(Xa, Xb), (Xa - f32(1e-2 * shrink)).astype(f32)).astype(f32) - m).astype(f32)
+        xh = (np.where(whole, np.maximum(Xa, Xb), (Xa + f32(1e-2 * shrink)).astype(f32)).astype(f32) + m).astype(f32)
         rows = np.arange(G, dtype=np.float32)[None, :]
-        zl = np.maximum(Zlo[:, None], rows - m[:, None]).astype(f32)
-        zh = np.minimum(Zhi[:, None], rows + f32(1.0) + m[:, None]).astype(f32)
-        xl = ((zl - Za[:, None]) * SL[:, None] + Xa[:, None]).astype(f32)
-        xh = ((zh - Za[:, None]) * SL[:, None] + Xa[:, None]).astype(f32)
-        whole = ~((np.abs(xl) < f32(1e30)) & (np.abs(xh) < f32(1e30)))
-        lo = np.where(whole, Xlo[:, None], np.maximum(np.minimum(xl, xh) - f32(1e-2 * shrink), Xlo[:, None])) - m[:, None]
-        hi = np.where(whole, Xhi[:, None], np.minimum(np.maximum(xl, xh) + f32(1e-2 * shrink), Xhi[:, None])) + m[:, None]
-        model_grid_cells.row_runs = (cl(lo.astype(f32)), cl(hi.astype(f32)))          # [rays, G] each; valid for rows iz0..iz1
+        fma = lambda a, b, c: (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(f32)   # (one rounding, like v_fma_f32)
+        dl = np.maximum(fma(sg[:, None], rows, alo[:, None]), dmin[:, None])
+        dh = np.minimum(fma(sg[:, None], rows, ahi[:, None]), dmax[:, None])
+        lo, hi = fma(dl, sl[:, None], xl[:, None]), fma(dh, sl[:, None], xh[:, None])
+        clc = lambda v: np.clip(np.floor(np.nan_to_num(v, nan=0.0, posinf=1e9, neginf=-1e9)).astype(np.int64), ix0[:, None], ix1[:, None])
+        model_grid_cells.row_runs = (clc(lo), clc(hi))          # [rays, G] each; valid for rows iz0..iz1
     kind = np.where(~sane, -1, np.where(miss, 0, np.where(far | bad, -1, 1)))
     return ix0, ix1, iz0, iz1, kind
 
