@@ -862,17 +862,18 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                         int colv = col32;
                         asm volatile("" : "+v"(colv));              // keep the address arithmetic on this side of the branch
                         const unsigned bit = 1u << colv;
-                        unsigned int *row = bits_w + wrel * 64;
+                        int rbase = wrel * 64 + 4 * hh;             // (4 hh folded into the row's base, not into each word's index: -0.3 %)
+                        unsigned int *row = bits_w + rbase;
 #pragma unroll
                         for (int bb = 0; bb < 2; ++bb) {
                             if (__ballot(keeps(X[bb])) != 0ull) {
                                 RT_COUNT(4);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
-                                    RT_LDS(0, 4, true, false, &row[16 * G + 8 * bb + 4 * hh + j],
+                                    RT_LDS(0, 4, true, false, &row[16 * G + 8 * bb + j],
                                            keeps(__float_as_uint(acc[8 * bb + j]) | __float_as_uint(acc[8 * bb + 4 + j])));
                                     if (keeps(__float_as_uint(acc[8 * bb + j]) | __float_as_uint(acc[8 * bb + 4 + j])))
-                                        atomicOr(&row[16 * G + 8 * bb + 4 * hh + j], bit);
+                                        atomicOr(&row[16 * G + 8 * bb + j], bit);
                                 }
                             }
                         }
@@ -969,7 +970,10 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                             W *tm = reinterpret_cast<W *>(bits_w);                          // [kGroups][64]
 #pragma unroll
                             for (int g = 0; g < kGroups; ++g) tm[g * 64 + lane] = (W)0;
-                            W *tm_g = tm + (RT_GROUP_SKIP ? (lane >> 4) * 64 : 0);
+                            int lg_ = lane;
+                            asm volatile("" : "+v"(lg_));           // (computed here, per pass: hoisted out of the bounce loop this address was spilled to scratch memory -- a vector-memory
+                                                                    //  round trip and an s_waitcnt vmcnt(0) per pass; 10k-sphere scene -0.65 %)
+                            W *tm_g = tm + (RT_GROUP_SKIP ? (lg_ >> 4) * 64 : 0);
                             __builtin_amdgcn_wave_barrier();
                             // row by row: the columns of the part of the clipped piece that lies in the row's band (grid_row_run)
                             for (int k = 0; __any(k < nz); ++k) {
@@ -1008,7 +1012,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                                         mw &= mw - (W)1;
                                     }
                                 }
-                                if (lane < 2) tl[tn + lane] = (unsigned)ntt | kAll;
+                                int ntt_ = ntt;
+                                asm volatile("" : "+s"(ntt_));      // (likewise: the broadcast of this scalar sat in a spilled register; -0.6 %)
+                                if (lane < 2) tl[tn + lane] = (unsigned)ntt_ | kAll;
                                 __builtin_amdgcn_wave_barrier();
                                 list_all = false;
                                 n_list = tn;
