@@ -398,7 +398,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     }
                 }
                 const uint32_t n_gen = min(64u, blk_end - blk_next);
-#ifndef RT_COUNT_ROWS
+#if !defined(RT_COUNT_ROWS) && !defined(RT_COUNT_ENUM)
                 RT_COUNT(1);
 #endif
                 if ((uint32_t)lane < n_gen) {
@@ -748,6 +748,10 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     const bool has = (summary | word) != 0u;
                     const unsigned long long m = __ballot(has);
                     if (m == 0ull) break;
+#ifdef RT_COUNT_ENUM
+                    RT_COUNT(1);
+                    RT_COUNT_N(6, __popcll(m));
+#endif
 #ifdef RT_LDS_CONFLICTS
                     if constexpr (TUBE) {
                         const bool need_ = has && word == 0u;
@@ -1338,7 +1342,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     double sx = u11_53(w.x, w.y), sy = u11_53(w.z, w.w), sz = u11_53(b1.x, b1.y);
                     bool ok = sx * sx + sy * sy + sz * sz < 1.0;
                     while (!ok) {
-#ifndef RT_COUNT_ROWS
+#if !defined(RT_COUNT_ROWS) && !defined(RT_COUNT_ENUM)
                         RT_COUNT(6);
 #endif
                         U4 b = philox4x32_10(pix_global, (uint32_t)s, ev + nblk, 0u, P.k0, P.k1);
@@ -1370,7 +1374,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     if (!ok) {
                         uint32_t c0 = w.w;                                       // the word left over from the block before
                         do {
-#ifndef RT_COUNT_ROWS
+#if !defined(RT_COUNT_ROWS) && !defined(RT_COUNT_ENUM)
                             RT_COUNT(6);
 #endif
                             U4 b = philox4x32_10(pix_global, (uint32_t)s, ev + nblk, 0u, P.k0, P.k1);
