@@ -8,8 +8,10 @@
 // Nothing here computes radiance.  (rtiow_amd/scene.py is the same mirror in Python; the two
 // build bit-identical scenes, tests/test_host_cpp.py.)
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <memory>
 #include <vector>
 
@@ -168,6 +170,75 @@ inline HittableList random_scene(uint64_t seed = 1, int lo = -11, int hi = 11)
     world.push(Sphere(Point3(-4, 1, 0), 1.0, std::make_shared<Lambertian>(Color(0.4, 0.2, 0.1))));
     world.push(Sphere(Point3(4, 1, 0), 1.0, std::make_shared<Metal>(Color(0.7, 0.6, 0.5), 0.0)));
     return world;
+}
+
+// ---- output stage: main.rs:147,177 `image_buffer.save("image.png")` ------------------------------------------------
+// An 8-bit RGBA PNG, rows top first (the order main.rs:141-145 produces), alpha as to_rgba() set it (255): the colour
+// type, bit depth and pixels of the file the reference saves through the `image` crate.  No zlib in the build: the
+// IDAT stream is zlib-framed DEFLATE in STORED blocks (RFC 1950/1951: legal for every decoder, 5 bytes of overhead per
+// 65 535 bytes), the CRC-32 of each chunk and the Adler-32 of the stream are computed here.
+inline uint32_t png_crc32(uint32_t crc, const unsigned char *p, size_t n)
+{
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+    return ~crc;
+}
+
+inline bool write_png(const char *path, const unsigned char *rgba_top_first, int width, int height)
+{
+    if (width < 1 || height < 1) return false;
+    auto be32 = [](std::vector<unsigned char> &v, uint32_t x) { for (int s = 24; s >= 0; s -= 8) v.push_back((unsigned char)(x >> s)); };
+    // the filtered image: a filter-type byte (0 = None) before each row
+    const size_t row = 4 * (size_t)width;
+    std::vector<unsigned char> raw;
+    raw.reserve((row + 1) * (size_t)height);
+    for (int y = 0; y < height; ++y) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgba_top_first + (size_t)y * row, rgba_top_first + ((size_t)y + 1) * row);
+    }
+    // zlib stream: CMF/FLG, stored blocks, Adler-32 (big-endian)
+    std::vector<unsigned char> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t pos = 0; pos < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n == raw.size() ? 1 : 0);                     // BFINAL, BTYPE = 00
+        z.push_back((unsigned char)(n & 0xFF)); z.push_back((unsigned char)(n >> 8));
+        z.push_back((unsigned char)(~n & 0xFF)); z.push_back((unsigned char)((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + (long)pos, raw.begin() + (long)(pos + n));
+        for (size_t i = pos; i < pos + n; ++i) { a += raw[i]; if (a >= 65521u) a -= 65521u; b += a; if (b >= 65521u) b -= 65521u; }
+        pos += n;
+    }
+    be32(z, (b << 16) | a);
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return false;
+    auto chunk = [&](const char tag[4], const std::vector<unsigned char> &body) {
+        std::vector<unsigned char> c;
+        be32(c, (uint32_t)body.size());
+        c.insert(c.end(), tag, tag + 4);
+        c.insert(c.end(), body.begin(), body.end());
+        const uint32_t crc = png_crc32(0u, c.data() + 4, c.size() - 4);
+        be32(c, crc);
+        return std::fwrite(c.data(), 1, c.size(), f) == c.size();
+    };
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+    bool ok = std::fwrite(sig, 1, 8, f) == 8;
+    std::vector<unsigned char> ihdr;
+    be32(ihdr, (uint32_t)width); be32(ihdr, (uint32_t)height);
+    ihdr.push_back(8); ihdr.push_back(6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);   // depth 8, RGBA, deflate, adaptive, no interlace
+    ok = ok && chunk("IHDR", ihdr) && chunk("IDAT", z) && chunk("IEND", {});
+    return (std::fclose(f) == 0) && ok;
 }
 
 } // namespace rtiow

@@ -1,11 +1,12 @@
 // rtiow_render -- the reference's main() (src/main.rs:104-177) on the GPU path: build the scene,
-// build the camera, render through the C ABI, flip + to_rgba, write the image (P6 PPM instead of
-// the image crate's PNG; no preview window).
+// build the camera, render through the C ABI, flip + to_rgba, save the image (main.rs:177 `image_buffer.save("image.png")`:
+// an RGBA8 PNG when --out ends in .png, else the same bytes without alpha as a P6 PPM; no preview window).
 //
 //   rtiow_render [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--scene-seed S]
-//                [--grid LO HI] [--device K] [--out image.ppm] [--dump-scene scene.bin] [--scene scene.bin]
+//                [--grid LO HI] [--device K] [--out image.png|image.ppm] [--dump-scene scene.bin] [--scene scene.bin]
 //                [--devices 0,1,..  [--tile-rows T] [--force-rccl]] [--uniform53]
 //   rtiow_render --reassembly-plan H T N     (no GPU: the strided copies that put N shards' rows back in image order)
+//   rtiow_render --test-png W H out.png      (no GPU: a fixed pattern through the PNG writer -- r = 7x + 13y, g = x ^ y, b = x y, mod 256, alpha 255)
 //
 // --devices: the frame's rows are dealt round-robin to one rt_context per listed device, each driven by
 // its own host thread, and gathered with ONE RCCL ncclGather to the first device (host/rtiow_multi.hpp).
@@ -40,6 +41,18 @@ int main(int argc, char **argv)
         for (int k = 0; k < n; ++k)
             for (const rtiow::RowCopy &c : rtiow::reassembly_plan(H, T, n, k))
                 std::printf("%d %d %d %d %d %d %d\n", k, c.dst_row, c.src_row, c.rows, c.pieces, c.dst_pitch_rows, c.src_pitch_rows);
+        return 0;
+    }
+    if (argc == 5 && !std::strcmp(argv[1], "--test-png")) {
+        const int W = std::atoi(argv[2]), H = std::atoi(argv[3]);
+        if (W < 1 || H < 1) { std::fprintf(stderr, "--test-png W H out.png: W, H >= 1\n"); return 2; }
+        std::vector<unsigned char> px((size_t)W * H * 4);
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                unsigned char *q = &px[((size_t)y * W + x) * 4];
+                q[0] = (unsigned char)(7 * x + 13 * y); q[1] = (unsigned char)(x ^ y); q[2] = (unsigned char)(x * y); q[3] = 255;
+            }
+        if (!rtiow::write_png(argv[4], px.data(), W, H)) { std::perror(argv[4]); return 1; }
         return 0;
     }
     for (int i = 1; i < argc; ++i) {
@@ -115,11 +128,15 @@ int main(int argc, char **argv)
         if (rc) return die("rt_resolve_rgba8", rc);
         rt_destroy(ctx);
     }
-    FILE *f = std::fopen(out.c_str(), "wb");
-    if (!f) { std::perror(out.c_str()); return 1; }
-    std::fprintf(f, "P6\n%d %d\n255\n", width, height);
-    for (size_t k = 0; k < npix; ++k) std::fwrite(&rgba[4 * k], 1, 3, f);
-    std::fclose(f);
+    if (out.size() >= 4 && out.compare(out.size() - 4, 4, ".png") == 0) {             // main.rs:177
+        if (!rtiow::write_png(out.c_str(), rgba.data(), width, height)) { std::perror(out.c_str()); return 1; }
+    } else {
+        FILE *f = std::fopen(out.c_str(), "wb");
+        if (!f) { std::perror(out.c_str()); return 1; }
+        std::fprintf(f, "P6\n%d %d\n255\n", width, height);
+        for (size_t k = 0; k < npix; ++k) std::fwrite(&rgba[4 * k], 1, 3, f);
+        std::fclose(f);
+    }
     std::printf("%dx%d spp %d: %llu rays, kernel %.3f ms (%.1f Msamples/s) -> %s\n", width, height, spp,
                 (unsigned long long)st.rays_traced, st.kernel_ms, npix * (double)spp / st.kernel_ms / 1e3, out.c_str());
     return 0;

@@ -29,6 +29,35 @@ def test_cpp_random_scene_equals_python(tmp_path, args, grid):
     assert got.tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("w,h", [(301, 207), (1, 1), (5, 40000)])
+def test_cpp_png_writer_on_a_fixed_pattern(tmp_path, w, h):
+    """host/rtiow_host.hpp write_png (no zlib: stored DEFLATE blocks, own CRC-32 and Adler-32): `--test-png` sends a fixed pattern through
+    it -- more than one 65 535-byte block, a single pixel, a tall image -- and rtiow_amd.read_png (zlib, CRCs checked) and PIL must get
+    the pattern back."""
+    out = str(tmp_path / "p.png")
+    subprocess.run([_cli(), "--test-png", str(w), str(h), out], check=True, capture_output=True)
+    y, x = np.mgrid[0:h, 0:w]
+    want = np.stack([(7 * x + 13 * y) & 255, (x ^ y) & 255, (x * y) & 255, np.full_like(x, 255)], -1).astype(np.uint8)
+    assert np.array_equal(rt.read_png(out), want)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    assert np.array_equal(np.array(Image.open(out)), want)
+
+
+@pytest.mark.gpu
+def test_cpp_cli_saves_the_references_image_png(tmp_path, renderer, book1_flat):
+    """main.rs:177: `--out image.png` holds the RGBA8 frame, rows top first, alpha 255 -- byte for byte the library's resolve."""
+    out = str(tmp_path / "image.png")
+    subprocess.run([_cli(), "--width", "160", "--height", "90", "--spp", "6", "--out", out], check=True, capture_output=True)
+    renderer.upload_scene(book1_flat)
+    _, fix, _ = renderer.render(rt.book1_camera(160, 90), rt.make_params(160, 90, 6))
+    want = renderer.resolve_rgba8(fix, 6, flip=True)
+    got = rt.read_png(out)
+    assert got.shape == (90, 160, 4) and (got[:, :, 3] == 255).all() and np.array_equal(got, want)
+
+
 @pytest.mark.gpu
 def test_cpp_cli_renders_the_same_image(tmp_path, renderer, book1_flat):
     out = str(tmp_path / "image.ppm")

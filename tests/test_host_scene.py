@@ -88,6 +88,71 @@ def test_ppm_roundtrip(tmp_path):
     assert np.array_equal(rt.read_ppm(str(path)), rgba[:, :, :3])
 
 
+def test_png_is_the_references_image_png(tmp_path):
+    """main.rs:147,177: the reference saves an 8-bit RGBA PNG, rows top first.  write_png() writes that colour type, bit depth and pixel
+    order; read_png() gets the pixels back, and so does an independent decoder (PIL, when the image has it)."""
+    import struct
+    rng = np.random.default_rng(3)
+    rgba = rng.integers(0, 256, (41, 67, 4), dtype=np.uint8)
+    rgba[:, :, 3] = 255
+    path = str(tmp_path / "image.png")
+    rt.write_png(path, rgba)
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n" and data[12:16] == b"IHDR"
+    w, h, depth, ctype, comp, flt, lace = struct.unpack(">IIBBBBB", data[16:29])
+    assert (w, h, depth, ctype, comp, flt, lace) == (67, 41, 8, 6, 0, 0, 0)          # RGBA8, non-interlaced
+    assert np.array_equal(rt.read_png(path), rgba)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    assert np.array_equal(np.array(Image.open(path)), rgba)
+
+
+def test_read_png_decodes_every_row_filter(tmp_path):
+    """read_png() against files whose rows use the filters an encoder may choose (Sub, Up, Average, Paeth): built here by filtering
+    by hand, so the decoder is checked on all five types without a third-party encoder."""
+    import struct, zlib
+    rng = np.random.default_rng(4)
+    h, w, c = 9, 13, 4
+    img = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+    flat = img.reshape(h, w * c).astype(np.int32)
+    raw = bytearray()
+    for y in range(h):
+        ft = y % 5
+        prev = flat[y - 1] if y else np.zeros(w * c, dtype=np.int32)
+        line = []
+        for i in range(w * c):
+            a = int(flat[y, i - c]) if i >= c else 0
+            b = int(prev[i])
+            cc = int(prev[i - c]) if i >= c else 0
+            pa, pb, pc = abs(b - cc), abs(a - cc), abs(a + b - 2 * cc)
+            pred = [0, a, b, (a + b) >> 1, a if (pa <= pb and pa <= pc) else (b if pb <= pc else cc)][ft]
+            line.append((int(flat[y, i]) - pred) & 255)
+        raw += bytes([ft]) + bytes(line)
+    chunk = lambda t, d: struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    path = str(tmp_path / "f.png")
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
+    assert np.array_equal(rt.read_png(path), img)
+
+
+def test_read_png_on_the_references_own_render():
+    """The one image the reference ships (rtiow_part1_final.png, written by the `image` crate's encoder): read_png() must give the sky rows
+    the committed fixture holds (tests/golden/ref_png_sky_rows.json, extracted with PIL).  Runs where the reference is present."""
+    import json
+    src = "/root/reference/rtiow_part1_final.png"
+    if not os.path.exists(src):
+        pytest.skip("the reference tree is not on this machine")
+    im = rt.read_png(src)
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_png_sky_rows.json")))
+    assert im.shape == (fx["height"], fx["width"], 4) and (im[:, :, 3] == 255).all()
+    for y, rgb in fx["constant_rows"].items():
+        assert (im[int(y), :, :3] == np.array(rgb, dtype=np.uint8)).all()
+    for pt in fx["points"]:
+        assert im[pt["y"], pt["x"], :3].tolist() == pt["rgb"]
+
+
 def test_scene_file_roundtrip(tmp_path, book1_flat):
     path = str(tmp_path / "scene.bin")
     rt.save_scene(path, rt.random_scene(1))

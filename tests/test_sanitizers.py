@@ -52,6 +52,12 @@ def test_cpp_host_under_asan_ubsan_builds_the_same_scene(tmp_path):
         assert got.tobytes() == rt.random_scene(seed, grid=grid).flatten().tobytes()
     r = subprocess.run([exe, "--reassembly-plan", "4320", "1", "8"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and len(r.stdout.splitlines()) == 8 and "runtime error" not in r.stderr, r.stderr[-2000:]
+    # the PNG writer (own CRC-32 / Adler-32 / stored-block framing) under the sanitizers: several blocks, and the smallest image
+    for w, h in ((301, 207), (1, 1)):
+        out = str(tmp_path / "p.png")
+        r = subprocess.run([exe, "--test-png", str(w), str(h), out], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-2000:]
+        assert rt.read_png(out).shape == (h, w, 4)
     # a truncated scene file is refused, not read past its end
     bad = str(tmp_path / "bad.bin")
     open(bad, "wb").write(b"\0" * 100)
