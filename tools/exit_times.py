@@ -1,5 +1,5 @@
 """Diagnostic (not a test): loads an RT_EXIT_TIMES build (RTIOW_LIB) and prints how far apart the waves of
-the persistent grid leave the kernel on cfg2 (100 MHz real-time clock)."""
+the persistent grid leave the kernel on cfg2 (SPP=... for another sample count; 100 MHz real-time clock)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa
@@ -9,7 +9,7 @@ import rtiow_amd as rt
 r = rt.Renderer(0)
 r.upload_scene(rt.random_scene(1).flatten())
 for _ in range(2):
-    sm, fix, st = r.render(rt.book1_camera(1200, 675), rt.make_params(1200, 675, 100), want_fix=False)
+    sm, fix, st = r.render(rt.book1_camera(1200, 675), rt.make_params(1200, 675, int(os.environ.get("SPP", "100"))), want_fix=False)
 out = (C.c_ulonglong * 8)()
 r._lib.rt_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 r._lib.rt_debug_phase_cycles(r._h, out)
