@@ -338,6 +338,13 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
 #define RT_LDS_N(site, n, BYTES, ATOMIC, LOAD64, byte_addr, active) do { } while (0)
 #endif
     for (;;) {
+        // Wave priorities through a pass (s_setprio): 1 from here -- taking samples, refill, camera rays, then the filter rows, the ground
+        // test and the tile list --, 3 in the tile loop (the matrix pipe is fed sooner and the other waves' vector work fills the time
+        // the MFMAs take), 2 while the candidates are enumerated, 1 in the pooled exact rounds, 0 while the hit is shaded (the redraw
+        // loop runs at a quarter of the lanes), 1 again for the finished samples' sums.  Measured against round 2's choice (1 in the
+        // tile loop, 0 elsewhere): 1200x675x500 50.30 -> 49.73 ms (-1.15 %), configs[1] 10.79 -> 10.69, 10k spheres -1.0 %; no
+        // priorities at all +1.1 %; a dozen other assignments within 0.3 % of this one or slower (profiles/r04_experiments.txt 30).
+        __builtin_amdgcn_s_setprio(1);
         RT_COUNT(0);
         // ---- (a) lanes without a path take the next camera rays of the wave's queue -------------------------
         // Starting a sample (item -> pixel, Philox, lens rejection, the f64 camera arithmetic: ~340 vector
@@ -1029,10 +1036,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 }
                 RT_STAMP(3);
                 RT_STAMP(5);
-                // waves in the tile loop issue ahead of their SIMD partners: the matrix pipe is fed sooner and the other
-                // waves' vector work fills the time the MFMAs take (measured: -1.4 % on configs[1])
                 for (int t0 = 0; t0 < n_list; t0 += kSeg / 2) {
-                    __builtin_amdgcn_s_setprio(1);              // (raised per segment: an empty list never raises it)
+                    __builtin_amdgcn_s_setprio(3);
                     const int nwords = min(kSeg / 2, n_list - t0);          // one bitmap word per 32-sphere tile
                     for (int w = 0; w < nwords; ++w) bits_w[w * 64 + lane] = 0u;
                     // the segment's tiles (and two more for the look-ahead), one per lane
@@ -1089,10 +1094,12 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     }
                     __builtin_amdgcn_wave_barrier();
                     RT_STAMP(6);
-                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_s_setprio(2);
                     enumerate(t0, nwords);
                 }
+                __builtin_amdgcn_s_setprio(1);
                 finish_pool();
+                __builtin_amdgcn_s_setprio(0);              // (the shading below)
                 }   // scan_mask != 0
             }
 #ifdef RTIOW_CROSSCHECK_MODES
@@ -1464,6 +1471,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             }
         }
         RT_STAMP(13);
+        __builtin_amdgcn_s_setprio(1);
         // ---- (f) finished samples -> their block's sums (LDS) or, without a ring entry, the frame buffer ----
         {
             // age of this lane's block among the wave's blocks (0 = the current one); blocks of age >= kRingDepth have
