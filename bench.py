@@ -179,6 +179,48 @@ def time_config(rt, torch, renderer, flat, w, h, spp, launches, stream):
                                                   / (k_ms * 1e-3) / 1e12, 1)}
 
 
+def end_to_end(rt, renderer, w, h, spp, calls):
+    """SURVEY.md 8(d)'s separate figure: wall time of the HOST-BUFFER calls a maintainer's binding makes for one frame
+    (main.rs:122-145: render, to_rgba, flip; scene upload excluded, buffers allocated beforehand, pageable like a Vec<u8>):
+    `one_call` = rt_render_rgba8 (sums stay on the device, 4 B/pixel back), `two_calls` = rt_render(out_fix) + rt_resolve_rgba8
+    (24 B/pixel out, 24 B/pixel in again, 4 B/pixel out: the path rounds 1-4 documented).  Mean of `calls` frames each, after one
+    warm-up frame; kernel_ms = the library's HIP events of the same launches."""
+    import ctypes as C
+    from rtiow_amd import _ffi
+    lib = _ffi.load()
+    cam = rt.book1_camera(w, h).to_rt_camera()
+    p = rt.make_params(w, h, spp, seed=1)
+    rgba = np.zeros((h, w, 4), dtype=np.uint8)
+    fix = np.zeros((h, w, 3), dtype=np.uint64)
+    st = _ffi.rt_stats()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def one():
+        _ffi.check(lib.rt_render_rgba8(renderer._h, C.byref(cam), C.byref(p), 1, vp(rgba), C.byref(st)), "rt_render_rgba8")
+
+    def two():
+        _ffi.check(lib.rt_render(renderer._h, C.byref(cam), C.byref(p), None, vp(fix), C.byref(st)), "rt_render")
+        _ffi.check(lib.rt_resolve_rgba8(renderer._h, vp(fix), w, h, spp, 1, vp(rgba)), "rt_resolve_rgba8")
+
+    out = {"width": w, "height": h, "spp": spp, "calls_timed": calls}
+    crc = {}
+    import zlib
+    for name, fn in (("one_call", one), ("two_calls", two)):
+        fn()
+        wall, kern = [], []
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            fn()
+            wall.append((time.perf_counter() - t0) * 1e3)
+            kern.append(st.kernel_ms)
+        crc[name] = zlib.crc32(rgba.tobytes())
+        out[name] = {"ms": round(float(np.mean(wall)), 3), "kernel_ms": round(float(np.mean(kern)), 3),
+                     "overhead_ms": round(float(np.mean(wall)) - float(np.mean(kern)), 3),
+                     "Msamples_per_s": round(w * h * spp / float(np.mean(wall)) / 1e3, 1)}
+    out["same_bytes"] = crc["one_call"] == crc["two_calls"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,6 +234,7 @@ def main():
                     help="rows per shard tile; 1 balances the ranks to within one row of each other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--weak-baseline", action="store_true",
                     help="N=1 only: the single-GPU half of SURVEY.md 8(e)'s weak-scaling pair -- BASELINE configs[2], "
                          "3840x2160x500 = 4.147 G samples, the per-GPU share of the N>1 runs -- as a whole step "
@@ -480,6 +523,19 @@ def main():
                 others.append({"error": str(e)})
             renderer.upload_scene(flat)
             out["other_configs"] = others
+        if world == 1 and is_default and not args.weak_baseline and not args.tenk and not args.no_end_to_end:
+            # the end-to-end figure through the host-buffer entry points (PCIe-inclusive; never `value`): what the
+            # reference's main() would see for the headline frame and for BASELINE configs[1]
+            try:
+                renderer.upload_scene(flat)
+                out["end_to_end"] = {
+                    "what": "wall ms per frame of the host-buffer C-ABI calls replacing main.rs:122-145 (scene upload excluded; "
+                            "pageable host buffers): one_call = rt_render_rgba8, two_calls = rt_render + rt_resolve_rgba8",
+                    "headline": end_to_end(rt, renderer, W, H, spp_frame, 5),
+                    "configs[1]": end_to_end(rt, renderer, 1200, 675, 100, 10),
+                }
+            except Exception as e:
+                out["end_to_end"] = {"error": str(e)}
         if per_rank is not None:
             out["per_rank"] = per_rank
         out["gather_ms"] = round(float(np.mean(gather_ms)), 3)       # rank 0, mean per timed step (at N = 1: the copy into frame order)

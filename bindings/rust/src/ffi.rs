@@ -1,4 +1,4 @@
-//! Raw FFI of `librtiow_hip.so` (C ABI: `include/rtiow_hip.h`, ABI version 4).
+//! Raw FFI of `librtiow_hip.so` (C ABI: `include/rtiow_hip.h`, ABI version 5).
 //!
 //! UNCOMPILED: there is no rustc/cargo in the build image of this repository, so this file has never
 //! been through a Rust compiler.  What IS checked (tests/test_rust_binding.py, CPU): every `#[repr(C)]`
@@ -8,13 +8,14 @@
 //!
 //! What the entry points stand in for in the reference (Druthyn/rtiow): the iterator expression at
 //! src/main.rs:122-139 (`rt_render`), `Color::to_rgba` src/vec3.rs:403-421 + the flip src/main.rs:141-145
-//! (`rt_resolve_rgba8`), the capture of `&world` at src/main.rs:135 (`rt_upload_scene`).
+//! (`rt_resolve_rgba8`), both in one call with the sums kept on the device (`rt_render_rgba8`: the bytes
+//! `ImageBuffer::from_vec` takes at src/main.rs:147), the capture of `&world` at src/main.rs:135 (`rt_upload_scene`).
 #![allow(non_camel_case_types, dead_code)]
 
 use core::mem::{offset_of, size_of};
 use std::os::raw::{c_char, c_void};
 
-pub const RTIOW_HIP_ABI_VERSION: i32 = 4;
+pub const RTIOW_HIP_ABI_VERSION: i32 = 5;
 
 pub const RT_OK: i32 = 0;
 pub const RT_ERR_INVALID_ARGUMENT: i32 = -1;
@@ -133,6 +134,8 @@ extern "C" {
                                    spp: i64, flip: i32, d_rgba: *mut c_void, stream: *mut c_void) -> i32;
     pub fn rt_resolve_rgba8(ctx: *mut rt_context, fix: *const u64, width: i32, rows: i32,
                             spp: i64, flip: i32, out_rgba: *mut u8) -> i32;
+    pub fn rt_render_rgba8(ctx: *mut rt_context, cam: *const rt_camera, p: *const rt_params, flip: i32,
+                           out_rgba: *mut u8, stats: *mut rt_stats) -> i32;
     pub fn rt_last_error() -> *const c_char;
     pub fn rt_backend_name() -> *const c_char;
     pub fn rt_abi_version() -> i32;

@@ -110,6 +110,18 @@ impl GpuRenderer {
         check(rc, "rt_resolve_rgba8")?;
         Ok(out)
     }
+
+    /// src/main.rs:122-145 in ONE call: render, `to_rgba` and the flip all on the device; only the RGBA8 bytes
+    /// (4 per pixel) cross PCIe.  Same bytes as `render` + `resolve_rgba8`, which move the 24-byte sums out and in again.
+    pub fn render_rgba8(&mut self, cam: &Camera, p: &rt_params, flip: bool) -> Result<(Vec<u8>, rt_stats), String> {
+        let mut rows = 0i32;
+        check(unsafe { rt_shard_rows(p, &mut rows) }, "rt_shard_rows")?;
+        let mut out = vec![0u8; rows as usize * p.width as usize * 4];
+        let mut stats: rt_stats = unsafe { std::mem::zeroed() };
+        let rc = unsafe { rt_render_rgba8(self.ctx, &cam.to_rt(), p, flip as i32, out.as_mut_ptr(), &mut stats) };
+        check(rc, "rt_render_rgba8")?;
+        Ok((out, stats))
+    }
 }
 
 impl Drop for GpuRenderer {
@@ -126,6 +138,6 @@ pub fn render_image(world: &HittableList, cam: &Camera, width: u32, height: u32,
     let p = rt_params { width: width as i32, height: height as i32, spp: spp as i32, sample_begin: 0, max_depth,
                         t_min: 0.0001,                  // main.rs:44
                         seed, tile_rows: 8, shard_index: 0, shard_count: 1, flags: 0 };
-    let (fix, _stats) = gpu.render(cam, &p)?;
-    gpu.resolve_rgba8(&fix, p.width, p.height, spp as i64, true)
+    let (pixels, _stats) = gpu.render_rgba8(cam, &p, true)?;      // (flip: top row first, main.rs:141-145)
+    Ok(pixels)
 }

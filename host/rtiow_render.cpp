@@ -4,10 +4,12 @@
 //
 //   rtiow_render [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--scene-seed S]
 //                [--grid LO HI] [--device K] [--out image.png|image.ppm] [--dump-scene scene.bin] [--scene scene.bin]
-//                [--devices 0,1,..  [--tile-rows T] [--force-rccl]] [--uniform53]
+//                [--devices 0,1,..  [--tile-rows T] [--force-rccl]] [--uniform53] [--two-calls]
 //   rtiow_render --reassembly-plan H T N     (no GPU: the strided copies that put N shards' rows back in image order)
 //   rtiow_render --test-png W H out.png      (no GPU: a fixed pattern through the PNG writer -- r = 7x + 13y, g = x ^ y, b = x y, mod 256, alpha 255)
 //
+// Single device: ONE call, rt_render_rgba8 (the sums stay on the device); --two-calls takes them through host memory
+// instead (rt_render, then rt_resolve_rgba8): the same bytes.
 // --devices: the frame's rows are dealt round-robin to one rt_context per listed device, each driven by
 // its own host thread, and gathered with ONE RCCL ncclGather to the first device (host/rtiow_multi.hpp).
 // A device may be listed more than once (two contexts on one GPU from two threads: the threading rule of
@@ -33,7 +35,7 @@ int main(int argc, char **argv)
     unsigned long long seed = 1, scene_seed = 1;
     std::string out = "image.ppm", dump, scene_file;
     std::vector<int> devices;                    // --devices 0,1,...: one context + host thread per entry
-    bool force_rccl = false, uniform53 = false;
+    bool force_rccl = false, uniform53 = false, two_calls = false;
     int tile_rows = 1;
     if (argc == 5 && !std::strcmp(argv[1], "--reassembly-plan")) {
         const int H = std::atoi(argv[2]), T = std::atoi(argv[3]), n = std::atoi(argv[4]);
@@ -69,6 +71,7 @@ int main(int argc, char **argv)
         else if (arg("--tile-rows")) tile_rows = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--force-rccl")) force_rccl = true;
         else if (!std::strcmp(argv[i], "--uniform53")) uniform53 = true;
+        else if (!std::strcmp(argv[i], "--two-calls")) two_calls = true;
         else if (arg("--dump-scene")) dump = argv[++i];
         else if (arg("--scene")) scene_file = argv[++i];
         else if (!std::strcmp(argv[i], "--grid") && i + 2 < argc) { lo = std::atoi(argv[++i]); hi = std::atoi(argv[++i]); }
@@ -121,11 +124,17 @@ int main(int argc, char **argv)
         if (rc) return die("rt_create", rc);
         rc = rt_upload_scene(ctx, flat.data(), (int32_t)flat.size());
         if (rc) return die("rt_upload_scene", rc);
-        std::vector<uint64_t> fix(npix * 3);
-        rc = rt_render(ctx, &rc_cam, &p, nullptr, fix.data(), &st);                  // main.rs:122-136
-        if (rc) return die("rt_render", rc);
-        rc = rt_resolve_rgba8(ctx, fix.data(), width, height, spp, 1, rgba.data());  // main.rs:137,141-145
-        if (rc) return die("rt_resolve_rgba8", rc);
+        if (two_calls) {                         // the sums through host memory: rt_render, then rt_resolve_rgba8 (same bytes)
+            std::vector<uint64_t> fix(npix * 3);
+            rc = rt_render(ctx, &rc_cam, &p, nullptr, fix.data(), &st);                  // main.rs:122-136
+            if (rc) return die("rt_render", rc);
+            rc = rt_resolve_rgba8(ctx, fix.data(), width, height, spp, 1, rgba.data());  // main.rs:137,141-145
+            if (rc) return die("rt_resolve_rgba8", rc);
+        } else {
+            // main.rs:122-145 in one call: the sums stay on the device, the flipped RGBA8 bytes come back
+            rc = rt_render_rgba8(ctx, &rc_cam, &p, 1, rgba.data(), &st);
+            if (rc) return die("rt_render_rgba8", rc);
+        }
         rt_destroy(ctx);
     }
     if (out.size() >= 4 && out.compare(out.size() - 4, 4, ".png") == 0) {             // main.rs:177

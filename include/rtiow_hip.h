@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RTIOW_HIP_ABI_VERSION 4
+#define RTIOW_HIP_ABI_VERSION 5
 
 typedef struct rt_context rt_context;
 
@@ -210,6 +210,17 @@ int rt_resolve_rgba8_device(rt_context *ctx, const void *d_fix, int32_t width, i
 /* Host-buffer form (copies in, resolves on the device, copies out). */
 int rt_resolve_rgba8(rt_context *ctx, const uint64_t *fix, int32_t width, int32_t rows,
                      int64_t spp, int32_t flip, uint8_t *out_rgba);
+
+/* ---- the whole of main.rs:122-145 in ONE call ------------------------------- */
+
+/* Renders (main.rs:122-136), keeps the exact sums ON THE DEVICE, puts them through Color::to_rgba with
+ * p->spp samples (main.rs:137, vec3.rs:403-421) and the row flip (main.rs:141-145, flip != 0), and copies the
+ * bytes out: out_rgba is [rows][width][4] u8, rows = rt_shard_rows() -- exactly the Vec<u8> that
+ * ImageBuffer::from_vec takes at main.rs:147.  4 bytes per pixel cross PCIe, once (rt_render + rt_resolve_rgba8
+ * move the 24-byte sums out and back in first).  Same bytes as that pair of calls.  Starts from zero
+ * (RT_FLAG_ACCUMULATE is ignored, as in rt_render); synchronous.  stats may be NULL. */
+int rt_render_rgba8(rt_context *ctx, const rt_camera *cam, const rt_params *p, int32_t flip,
+                    uint8_t *out_rgba, rt_stats *stats);
 
 /* ---- misc ------------------------------------------------------------------ */
 const char *rt_last_error(void);

@@ -57,6 +57,7 @@ SYMBOLS = [
     ("rt_last_stats", C.c_int, [_VP, C.POINTER(rt_stats)]),
     ("rt_resolve_rgba8_device", C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _VP, _VP]),
     ("rt_resolve_rgba8", C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _VP]),
+    ("rt_render_rgba8", C.c_int, [_VP, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_int32, _VP, C.POINTER(rt_stats)]),
     ("rt_last_error", C.c_char_p, []),
     ("rt_backend_name", C.c_char_p, []),
     ("rt_abi_version", C.c_int32, []),

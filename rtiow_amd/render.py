@@ -125,6 +125,18 @@ class Renderer:
                                        C.byref(st)), "rt_render")
         return out_sum, out_fix, stats_dict(st)
 
+    # -- main.rs:122-145 in one call ---------------------------------------------
+    def render_rgba8(self, cam, params, flip=True):
+        """Render + Color::to_rgba + flip with the sums kept on the device (rt_render_rgba8): returns
+        (RGBA8 [rows,W,4] -- the bytes ImageBuffer::from_vec takes at main.rs:147 --, stats dict)."""
+        rc = cam.to_rt_camera() if hasattr(cam, "to_rt_camera") else cam
+        rows = shard_rows(params)
+        out = np.zeros((rows, params.width, 4), dtype=np.uint8)
+        st = _ffi.rt_stats()
+        _ffi.check(self._lib.rt_render_rgba8(self._h, C.byref(rc), C.byref(params), int(bool(flip)),
+                                             out.ctypes.data_as(C.c_void_p), C.byref(st)), "rt_render_rgba8")
+        return out, stats_dict(st)
+
     # -- device-buffer render (pointers come from e.g. torch tensors) ---------
     def render_device(self, cam, params, d_fix_ptr, stream=0):
         rc = cam.to_rt_camera() if hasattr(cam, "to_rt_camera") else cam

@@ -55,7 +55,7 @@ def test_struct_layouts_match_the_header():
 def test_identity():
     lib = _ffi.load()
     assert lib.rt_backend_name() == b"hip-gfx950"
-    assert lib.rt_abi_version() == 4
+    assert lib.rt_abi_version() == 5
     # the library on disk was built from the kernel sources of this tree (a stale .so would carry another sha)
     import bench
     assert lib.rt_build_source_sha().decode() == bench.kernel_source_sha(), "stale rtiow_amd/librtiow_hip.so: run ./build_lib.sh"
@@ -82,6 +82,7 @@ def test_null_arguments_are_errors_not_crashes():
     assert lib.rt_create(0, None) == -1
     assert lib.rt_destroy(None) == 0
     assert lib.rt_upload_scene(None, None, 0) == -1
+    assert lib.rt_render_rgba8(None, None, None, 1, None, None) == -1
 
 
 def _gpu_present():
