@@ -221,6 +221,35 @@ def end_to_end(rt, renderer, w, h, spp, calls):
     return out
 
 
+def weak_efficiency(ms_per_step, samples_per_gpu, sha, rehearsal):
+    """The north_star's second number at N > 1: T(1 GPU) / T(N GPUs) at the same samples per GPU (configs[2] on one
+    GPU against configs[4]'s geometry on N).  T(1) is not measured in an N > 1 run: it is read from the newest committed
+    `bench.py --weak-baseline` line (profiles/r??_bench_weak_baseline.json) -- a CROSS-RUN ratio, labelled as such; the driver
+    forms its own from its back-to-back N = 1, 2, 4, 8 values."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_weak_baseline.json")))
+    if not files:
+        return {"value": None, "note": "no profiles/r??_bench_weak_baseline.json to compare with"}
+    try:
+        base = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+        t1 = float(base["ms_per_step"])
+        spg = int(base["config"]["samples_per_gpu"])
+    except Exception as e:
+        return {"value": None, "note": f"unreadable {os.path.basename(files[-1])}: {e}"}
+    out = {"value": None, "baseline_ms_per_step": t1, "baseline_samples_per_gpu": spg,
+           "baseline_source": os.path.relpath(files[-1], ROOT), "baseline_kernel_source_sha": base["config"].get("kernel_source_sha"),
+           "kind": "cross-run: T(N = 1) from the committed --weak-baseline line (another box, another day), T(N) from this run"}
+    if rehearsal:
+        out["note"] = "rehearsal on one GPU: the ranks share a device, no efficiency is formed"
+    elif spg != samples_per_gpu:
+        out["note"] = f"this run traces {samples_per_gpu} samples per GPU, the baseline {spg}: not a weak-scaling pair"
+    else:
+        out["value"] = round(t1 / ms_per_step, 4)
+        if out["baseline_kernel_source_sha"] != sha:
+            out["note"] = "the baseline line was taken on other kernel sources than this run's"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -538,6 +567,8 @@ def main():
                 out["end_to_end"] = {"error": str(e)}
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if world > 1:
+            out["weak_efficiency"] = weak_efficiency(elapsed / args.steps * 1e3, frame_samples // world, sha, rehearse)
         out["gather_ms"] = round(float(np.mean(gather_ms)), 3)       # rank 0, mean per timed step (at N = 1: the copy into frame order)
         out["rmse_vs_cpu"] = None
         if world == 1 and not args.no_cpu_baseline:

@@ -143,6 +143,8 @@ extern "C" {
     pub fn rt_f64_div_sqrt_device(ctx: *mut rt_context, a: *const f64, b: *const f64, n: i32,
                                   out_div: *mut f64, out_sqrt: *mut f64) -> i32;
     pub fn rt_quantize_device(ctx: *mut rt_context, x: *const f64, n: i32, out: *mut u64) -> i32;
+    pub fn rt_unit_accept_device(ctx: *mut rt_context, words: *const u32, n: i32, out_accept: *mut u32,
+                                 out_uniforms: *mut f64) -> i32;
     pub fn rt_filter_tube_device(ctx: *mut rt_context, o: *const f64, d: *const f64, spheres32: *const rt_sphere,
                                  out_h: *mut f32, out_rows: *mut f32, out_bound: *mut f32, out_rho: *mut f32) -> i32;
     pub fn rt_tube_tile_host(spheres32: *const rt_sphere, out_words: *mut u32, out_bound: *mut f32,

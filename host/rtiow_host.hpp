@@ -179,16 +179,17 @@ inline HittableList random_scene(uint64_t seed = 1, int lo = -11, int hi = 11)
 // 65 535 bytes), the CRC-32 of each chunk and the Adler-32 of the stream are computed here.
 inline uint32_t png_crc32(uint32_t crc, const unsigned char *p, size_t n)
 {
-    static uint32_t table[256];
-    static bool ready = false;
-    if (!ready) {
+    struct Table { uint32_t t[256]; };
+    static const Table tab = [] {                                       // (function-local static: initialised once, thread-safe)
+        Table x{};
         for (uint32_t i = 0; i < 256; ++i) {
             uint32_t c = i;
             for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-            table[i] = c;
+            x.t[i] = c;
         }
-        ready = true;
-    }
+        return x;
+    }();
+    const uint32_t *table = tab.t;
     crc = ~crc;
     for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
     return ~crc;
@@ -221,6 +222,7 @@ inline bool write_png(const char *path, const unsigned char *rgba_top_first, int
         pos += n;
     }
     be32(z, (b << 16) | a);
+    if (z.size() > 0x7fffffffu) return false;                           // a PNG chunk's length field holds at most 2^31 - 1 (one IDAT chunk here)
     FILE *f = std::fopen(path, "wb");
     if (!f) return false;
     auto chunk = [&](const char tag[4], const std::vector<unsigned char> &body) {

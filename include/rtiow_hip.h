@@ -18,9 +18,11 @@
  *     rt_last_error() gives the thread-local message of the last failure;
  *   - the caller owns every buffer it passes; the library owns the device
  *     memory tied to an rt_context;
- *   - a context is used from one host thread at a time and has ONE render in
- *     flight at a time (the work counter and statistics words belong to the
- *     context); distinct contexts (one per GPU) may be used concurrently;
+ *   - a context is used from one host thread at a time; it may have TWO
+ *     renders in flight (rt_render_device on two different streams: the work
+ *     counter, statistics words and events exist twice and are used in turn --
+ *     see rt_render_device); distinct contexts (one per GPU) may be used
+ *     concurrently;
  *   - there is NO CPU fallback: without a usable gfx950 device rt_create fails.
  *
  * Arithmetic.  Results are those of the reference's own f64 arithmetic: every
@@ -110,7 +112,8 @@ typedef struct {
 #define RT_FLAG_NO_FILTER  0x2u  /* validation: send EVERY sphere to the exact f64 test     */
 #define RT_FLAG_DIAG_STATS 0x4u  /* also fill rt_stats.candidates / exact_roots / live_per_bounce (~15 % slower) */
 #define RT_FLAG_UNIFORM53  0x8u  /* every uniform from TWO Philox words, u = ((w0 << 32 | w1) >> 11) * 2^-53: the 53 random bits of
-                                    rand's gen::<f64>() (main.rs:131-132, vec3.rs:31-33,63, materials.rs:96) instead of 24; same draw
+                                    rand's gen::<f64>() (main.rs:131-132, vec3.rs:31-33,63, materials.rs:96) instead of one word's 32
+                                    (the default: u = w * 2^-32, symmetric ranges (int32_t)w * 2^-31; ABI <= 4: 24 bits); same draw
                                     order; another (equally valid) random stream, so frames differ from the default's; scan mode 5 or
                                     RT_FLAG_NO_FILTER, not with RT_FLAG_DIAG_STATS */
 
@@ -155,9 +158,12 @@ int rt_destroy(rt_context *ctx);
 
 /* ---- scene: stands in for `&world` captured at main.rs:135 ----------------- */
 /* The reference's list is a Vec<Box<dyn Hit>> of any length (shapes/mod.rs:52).  Here n <= RT_MAX_SPHERES: the
- * kernel numbers the columns of its filter table in 26 bits, and a table holds at most ~2 columns per sphere.
- * (Rounds 1-3 stopped at 65 535: 16-bit candidate numbers.)  Coordinates and radii must be finite and below
- * 1e15 in magnitude, radii non-zero, kinds RT_LAMBERTIAN / RT_METAL / RT_DIALECTRIC. */
+ * kernel numbers the columns of its filter table in 26 bits.  (Rounds 1-3 stopped at 65 535: 16-bit candidate numbers.)
+ * A performance cliff sits far below the limit: the tile grid has at most 63 x 63 cells of 32 columns (+ 48 tiles every ray
+ * scans), i.e. ~128 K columns; a scene that needs more -- upwards of ~130 000 filtered spheres -- gets NO grid, every wave
+ * then scans all n/32 tiles per bounce (O(n) per ray, still exact: tests/test_limits.py renders 70 227 spheres both ways).
+ * Coordinates and radii must be finite and below 1e15 in magnitude, radii non-zero, kinds RT_LAMBERTIAN / RT_METAL /
+ * RT_DIALECTRIC. */
 #define RT_MAX_SPHERES (1 << 24)
 int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n);
 
@@ -172,10 +178,11 @@ int rt_shard_row_index(const rt_params *p, int32_t compact_row, int32_t *out_j);
  * (main.rs:127,135), unbounded.  Here one channel of one sample enters the pixel's sum as
  *     q = floor(min(x, RT_SAMPLE_CLAMP) * 2^32)   (0 for a NaN or a negative x)
  * and the sums are u64: exact, associative, identical however the samples are spread over lanes, launches or GPUs.
- * With q <= 2^48 a sum CANNOT wrap while a pixel has received at most 65 536 samples (all launches that accumulate
- * into the same buffer together), whatever the scene; and within that limit the clamp cannot change a byte of
+ * With q <= 2^48 a sum CANNOT wrap while a pixel has received FEWER THAN 65 536 samples (at most 65 535: all launches
+ * that accumulate into the same buffer together; 65 536 saturated samples would sum to exactly 2^64), whatever the scene;
+ * and within that limit the clamp cannot change a byte of
  * Color::to_rgba: a clamped sample alone puts the pixel's mean at >= 1, i.e. at byte 255, where the reference's
- * unbounded sum puts it too.  Beyond 65 536 samples per pixel the sums stay exact while the pixel's mean radiance is
+ * unbounded sum puts it too.  From 65 536 samples per pixel on the sums stay exact while the pixel's mean radiance is
  * below 2^32 / samples; a scene whose albedos are <= 1 (every scene of the reference) has x <= 1 and no limit below
  * 2^32 samples.  (Rounds 1-3 clamped at 2^30: four saturated samples wrapped a sum.) */
 #define RT_SAMPLE_CLAMP 65536.0
@@ -188,7 +195,14 @@ int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *p,
               float *out_sum, uint64_t *out_fix, rt_stats *stats);
 
 /* Device-buffer form, asynchronous on `stream` (a hipStream_t, or NULL for the
- * default stream).  d_fix: device pointer to [rows][width][3] u64. */
+ * default stream).  d_fix: device pointer to [rows][width][3] u64.
+ * Progressive passes (main.rs:130-137 split over launches with sample_begin and RT_FLAG_ACCUMULATE): the sums are exact
+ * integers added with atomics, so passes may OVERLAP -- issue pass k + 1 on another stream than pass k and it fills the tail
+ * of pass k (the last paths of a launch leave most of the chip idle: 5 % of a 100-spp launch at 1200x675).  A context holds
+ * the per-launch state of two launches; a third launch makes ITS stream wait for the one before the previous (no host wait).
+ * The caller orders what must be ordered: the buffer is zeroed (by a launch without RT_FLAG_ACCUMULATE, or by the caller)
+ * before any other stream adds to it, and it is read after every stream that adds to it has been waited for.
+ * rt_last_stats reports on the latest launch only. */
 int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p,
                      void *d_fix, void *stream);
 
@@ -237,6 +251,12 @@ int rt_f64_div_sqrt_device(rt_context *ctx, const double *a, const double *b, in
 /* ... and the kernel's quantisation of one radiance channel to the exact 2^-32 grid (contract C5, DESIGN.md
  * section 4): out[i] = floor(min(x[i], RT_SAMPLE_CLAMP) * 2^32) for x[i] >= 0, and 0 for negatives and NaN. */
 int rt_quantize_device(rt_context *ctx, const double *x, int32_t n, uint64_t *out);
+/* ... and the kernel's rejection tests and word -> draw rules on n triples (wx, wy, wz) of Philox words: u01(w) = w * 2^-32 (draws
+ * from [0,1)), u11(w) = (int32_t)w * 2^-31 (draws from (-1..1) and (-1..=1): the word as a two's-complement integer).  out_accept[k]
+ * bit 0 = random_in_unit_sphere's `length_squared() < 1.0` (vec3.rs:37-45) for (u11(wx), u11(wy), u11(wz)), bit 1 =
+ * random_in_unit_disk's (vec3.rs:59-68) for (u11(wx), u11(wy)), as the retry loops decide them (on the integers behind the draws,
+ * with the f64 expression where its roundings could decide: DESIGN.md section 3); out_uniforms[k] = (u01(wx), u11(wx), u11(wy), u11(wz)). */
+int rt_unit_accept_device(rt_context *ctx, const uint32_t *words, int32_t n, uint32_t *out_accept, double *out_uniforms);
 /* Known-answer hooks of the EARLIER matrix-pipe forms of the filter (scan modes 2-4).
  * They exist only in a library built with -DRTIOW_CROSSCHECK_MODES (tools/librtiow_hip_xcheck.so, a test
  * artefact); the product library carries scan modes 0, 1 and 5 and does not export them. */

@@ -187,8 +187,9 @@ def camera_from_host(cam):
     return c
 
 
-def uniforms(seed, pixel, sample, count, uniform53=False):
-    """The first `count` uniforms of the stream of (pixel, sample), taken as one run."""
+def uniforms(seed, pixel, sample, count, uniform53=False, symmetric=False):
+    """The first `count` draws of the stream of (pixel, sample), taken as one run: from [0,1), or (symmetric) from (-1..1)."""
     out = np.zeros(count, dtype=np.float64)
-    load().oracle_uniforms(seed, pixel, sample, FLAG_UNIFORM53 if uniform53 else 0, count, out.ctypes.data_as(C.c_void_p))
+    flags = (FLAG_UNIFORM53 if uniform53 else 0) | (0x100 if symmetric else 0)
+    load().oracle_uniforms(seed, pixel, sample, flags, count, out.ctypes.data_as(C.c_void_p))
     return out

@@ -69,7 +69,7 @@ typedef struct {
     uint32_t flags;         /* ORACLE_FLAG_*                            */
 } oracle_params;
 /* Every uniform from TWO consecutive Philox words, u = ((w0 << 32 | w1) >> 11) * 2^-53 (the 53 random bits of rand 0.8.5's
- * gen::<f64>(), main.rs:131-132, vec3.rs:31-33,63, materials.rs:96) instead of one word's 24 bits; same draw order, same
+ * gen::<f64>(), main.rs:131-132, vec3.rs:31-33,63, materials.rs:96) instead of one word's 32 bits; same draw order, same
  * runs of consecutive words (oracle_common.h).  Mirrors RT_FLAG_UNIFORM53 of include/rtiow_hip.h. */
 #define ORACLE_FLAG_UNIFORM53 0x8u
 
@@ -130,7 +130,9 @@ void oracle_to_rgba(const double c[3], int64_t spp, uint8_t out[4]);
 void oracle_get_ray(const oracle_camera *cam, double s, double t, double lens_x, double lens_y,
                     double orig[3], double dir[3]);
 
-/* first `count` uniforms of the stream of (pixel, sample) as one run (24-bit, or 53-bit with ORACLE_FLAG_UNIFORM53) */
+/* first `count` draws of the stream of (pixel, sample) as one run: from [0,1) (u = w * 2^-32; 53-bit with ORACLE_FLAG_UNIFORM53),
+ * or with ORACLE_FLAG_SYMMETRIC_DRAWS (this hook only) from the symmetric ranges (x = (int32_t)w * 2^-31; 2u - 1 with 53 bits) */
+#define ORACLE_FLAG_SYMMETRIC_DRAWS 0x100u
 void oracle_uniforms(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t flags, int32_t count, double *out);
 
 int oracle_hardware_threads(void);

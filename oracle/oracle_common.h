@@ -13,9 +13,13 @@
  * The Philox4x32-10 blocks B_0, B_1, ... of one (pixel, sample) are consumed in RUNS of consecutive
  * words (see oracle_rng below): the camera run, one run per Lambertian/Metal scatter, one per
  * Dialectric reflectance draw.
- * A 32-bit word w becomes the uniform u = (w >> 8) * 2^-24 in [0,1): exactly representable in f32
- * and f64, so A and B consume identical numbers.  With ORACLE_FLAG_UNIFORM53 a uniform takes TWO
- * consecutive words, u = ((w0 << 32 | w1) >> 11) * 2^-53.
+ * A 32-bit word w becomes a draw from [0,1) (gen::<f64>(): main.rs:131-132, materials.rs:96) as
+ * u = w * 2^-32, and a draw from the symmetric ranges (gen_range(-1.0..1.0) vec3.rs:63, (-1.0..=1.0)
+ * vec3.rs:31-33) as x = (int32_t)w * 2^-31 in [-1,1): the word read as an unsigned resp. a two's-complement
+ * integer -- all 32 bits of it either way, exactly representable in f64, so A and B consume identical
+ * numbers.  (Rounds 1-4 used u = (w >> 8) * 2^-24 and 2u - 1, a leftover of the abandoned f32 plan.)
+ * With ORACLE_FLAG_UNIFORM53 a draw takes TWO consecutive words, u = ((w0 << 32 | w1) >> 11) * 2^-53,
+ * and the symmetric ranges are 2u - 1.
  */
 #ifndef RTIOW_ORACLE_COMMON_H
 #define RTIOW_ORACLE_COMMON_H
@@ -79,7 +83,7 @@ static inline uint32_t rng_word(oracle_rng *r)
     return r->w[4 - r->have--];
 }
 
-/* Next `count` words of the current run as uniforms k * 2^-24 (exact in f64). */
+/* Next `count` words of the current run as uniforms w * 2^-32 (exact in f64). */
 static inline void rng_take(oracle_rng *r, int count, double *u)
 {
     if (r->explicit_u) {
@@ -94,9 +98,20 @@ static inline void rng_take(oracle_rng *r, int count, double *u)
             const uint64_t hi = rng_word(r), lo = rng_word(r);
             u[i] = (double)(((hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
         } else {
-            u[i] = (double)(rng_word(r) >> 8) * (1.0 / 16777216.0);
+            u[i] = (double)rng_word(r) * (1.0 / 4294967296.0);
         }
     }
+}
+/* Next `count` draws of the current run from the symmetric ranges (-1..1) / (-1..=1): one word each, read as a
+ * two's-complement integer, x = (int32_t)w * 2^-31 (exact); 2u - 1 for 53-bit draws and for explicit lists of uniforms. */
+static inline void rng_take_sym(oracle_rng *r, int count, double *x)
+{
+    if (r->explicit_u || r->u53) {
+        rng_take(r, count, x);
+        for (int i = 0; i < count; ++i) x[i] = 2.0 * x[i] - 1.0;
+        return;
+    }
+    for (int i = 0; i < count; ++i) x[i] = (double)(int32_t)rng_word(r) * (1.0 / 2147483648.0);
 }
 static inline void rng_end_run(oracle_rng *r) { r->have = 0; }
 

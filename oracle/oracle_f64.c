@@ -56,13 +56,13 @@ static inline vec3 refract(vec3 uv, vec3 n, double etai_over_etat)
 }
 
 /* random_in_range(-1,1) components (:26-35) and random_in_unit_sphere (:37-45):
- * one run of (x,y,z) tries, three consecutive words each; gen_range(-1.0..=1.0) -> 2u-1. */
+ * one run of (x,y,z) tries, three consecutive words each; gen_range(-1.0..=1.0) -> rng_take_sym. */
 static vec3 random_in_unit_sphere(oracle_rng *rng)
 {
     for (;;) {
         double u[3];
-        rng_take(rng, 3, u);
-        vec3 p = v3(2.0 * u[0] - 1.0, 2.0 * u[1] - 1.0, 2.0 * u[2] - 1.0);
+        rng_take_sym(rng, 3, u);
+        vec3 p = v3(u[0], u[1], u[2]);
         if (length_squared(p) < 1.0) { rng_end_run(rng); return p; }
     }
 }
@@ -222,14 +222,15 @@ static ray sample_ray(const oracle_camera *cam, const oracle_params *p, int i, i
     rng_init(rng, p->seed, (uint32_t)j * (uint32_t)p->width + (uint32_t)i, (uint32_t)s);
     rng->u53 = (p->flags & ORACLE_FLAG_UNIFORM53) != 0;
     double e[4];
-    rng_take(rng, 4, e);                                       /* B_0: one run with the lens tries that follow */
+    rng_take(rng, 2, e);                                       /* B_0: one run with the lens tries that follow */
+    rng_take_sym(rng, 2, e + 2);
     double u = ((double)i + e[0]) / (double)(p->width - 1);    /* main.rs:131 */
     double v = ((double)j + e[1]) / (double)(p->height - 1);   /* main.rs:132 */
-    /* random_in_unit_disk, vec3.rs:59-68: gen_range(-1.0..1.0) -> 2u-1 */
-    double lx = 2.0 * e[2] - 1.0, ly = 2.0 * e[3] - 1.0;
+    /* random_in_unit_disk, vec3.rs:59-68: gen_range(-1.0..1.0) -> rng_take_sym */
+    double lx = e[2], ly = e[3];
     while (!(length_squared(v3(lx, ly, 0.0)) < 1.0)) {
-        rng_take(rng, 2, e);
-        lx = 2.0 * e[0] - 1.0; ly = 2.0 * e[1] - 1.0;
+        rng_take_sym(rng, 2, e);
+        lx = e[0]; ly = e[1];
     }
     rng_end_run(rng);
     return get_ray(cam, u, v, lx, ly);
@@ -540,5 +541,6 @@ void oracle_uniforms(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t fl
     oracle_rng rng;
     rng_init(&rng, seed, pixel, sample);
     rng.u53 = (flags & ORACLE_FLAG_UNIFORM53) != 0;
-    rng_take(&rng, count, out);
+    if (flags & ORACLE_FLAG_SYMMETRIC_DRAWS) rng_take_sym(&rng, count, out);
+    else rng_take(&rng, count, out);
 }

@@ -65,6 +65,7 @@ SYMBOLS = [
     ("rt_philox_device", C.c_int, [_VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("rt_f64_div_sqrt_device", C.c_int, [_VP, _VP, _VP, C.c_int32, _VP, _VP]),
     ("rt_quantize_device", C.c_int, [_VP, _VP, C.c_int32, _VP]),
+    ("rt_unit_accept_device", C.c_int, [_VP, _VP, C.c_int32, _VP, _VP]),
     ("rt_tube_tile_host", C.c_int, [C.POINTER(rt_sphere), _VP, _VP, C.POINTER(C.c_float)]),
     ("rt_tile_layout_host", C.c_int, [C.POINTER(rt_sphere), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int32]),
     ("rt_filter_tube_device", C.c_int, [_VP, _VP, _VP, C.POINTER(rt_sphere), _VP, _VP, _VP, C.POINTER(C.c_float)]),

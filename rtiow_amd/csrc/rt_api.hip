@@ -73,6 +73,15 @@ struct rt_context {
     int scan_mode = 5;             // filter: 5 tube bf16x2 MFMA (default, shipped), 1 VALU + scalar loads (cross-check);
                                    // with -DRTIOW_CROSSCHECK_MODES also 2 f32 MFMA, 3 bf16x3 MFMA, 4 lifted bf16x3 MFMA
     int n_spheres = -1;
+    // Per-launch state -- the work counter, the statistics words and the two events -- exists kSlots times, used in turn: a context
+    // may have kSlots renders in flight (on different streams: the second fills the first one's end-of-launch tail); the fields
+    // below name the slot of the LATEST launch, which is what rt_last_stats reports on.
+    static constexpr int kSlots = 2;
+    unsigned int *q_slots[kSlots] = {nullptr, nullptr};
+    unsigned long long *s_slots[kSlots] = {nullptr, nullptr};
+    hipEvent_t e0_slots[kSlots] = {nullptr, nullptr}, e1_slots[kSlots] = {nullptr, nullptr};
+    bool slot_used[kSlots] = {false, false};
+    int cur = 0;
     unsigned int *d_queue = nullptr;
     unsigned long long *d_stats = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -508,10 +517,16 @@ int rt_create(int32_t device_id, rt_context **out)
                     "a -DRTIOW_CROSSCHECK_MODES build)", asked);
     }
 #endif
-    hipError_t e1 = hipMalloc((void **)&ctx->d_queue, 64);
-    hipError_t e2 = hipMalloc((void **)&ctx->d_stats, 1024);
-    hipError_t e3 = hipEventCreate(&ctx->ev0);
-    hipError_t e4 = hipEventCreate(&ctx->ev1);
+    hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess, e4 = hipSuccess;
+    for (int k = 0; k < rt_context::kSlots; ++k) {
+        hipError_t a = hipMalloc((void **)&ctx->q_slots[k], 64), b = hipMalloc((void **)&ctx->s_slots[k], 1024);
+        hipError_t c = hipEventCreate(&ctx->e0_slots[k]), d = hipEventCreate(&ctx->e1_slots[k]);
+        if (a != hipSuccess) e1 = a;
+        if (b != hipSuccess) e2 = b;
+        if (c != hipSuccess) e3 = c;
+        if (d != hipSuccess) e4 = d;
+    }
+    ctx->d_queue = ctx->q_slots[0]; ctx->d_stats = ctx->s_slots[0]; ctx->ev0 = ctx->e0_slots[0]; ctx->ev1 = ctx->e1_slots[0];
     hipError_t e5 = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
         rt_destroy(ctx);
@@ -527,10 +542,12 @@ int rt_destroy(rt_context *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     free_scene(ctx);
-    (void)hipFree(ctx->d_queue); (void)hipFree(ctx->d_stats);
+    for (int k = 0; k < rt_context::kSlots; ++k) {
+        (void)hipFree(ctx->q_slots[k]); (void)hipFree(ctx->s_slots[k]);
+        if (ctx->e0_slots[k]) (void)hipEventDestroy(ctx->e0_slots[k]);
+        if (ctx->e1_slots[k]) (void)hipEventDestroy(ctx->e1_slots[k]);
+    }
     (void)hipFree(ctx->d_stage_fix); (void)hipFree(ctx->d_stage_sum); (void)hipFree(ctx->d_stage_rgba);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return RT_OK;
@@ -739,7 +756,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     const unsigned long long n_blocks = (total_items + item_block - 1) / item_block;
     if (n_blocks > 0x7fffffffULL)
         return fail(RT_ERR_INVALID_ARGUMENT, "rows*width*spp = %llu pixel-samples in one launch: at most 2^31 blocks of %d "
-                    "(split the samples over several launches with sample_begin and RT_FLAG_ACCUMULATE)", total_items, rt::kItemBlock);
+                    "(split the samples over several launches with sample_begin and RT_FLAG_ACCUMULATE)", total_items, (int)item_block);
     rt::KParams kp;
     memset(&kp, 0, sizeof(kp));
     static_assert(sizeof(rt::KCamera) == sizeof(rt_camera), "camera layouts must match");
@@ -753,7 +770,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.npix = (uint32_t)npix; kp.total_items = total_items; kp.n_blocks = (uint32_t)n_blocks;
     kp.inv_spp = p->spp > 0 ? 1.0 / (double)p->spp : 0.0;
     kp.inv_width = 1.0 / (double)p->width;
-    // udiv_small (rt_kernels.hpp): numerators are < d + 256 (spp, width) or < 65536 (rows / tile_rows), so for
+    // udiv_small (rt_kernels.hpp): numerators are < d + kItemBlockLarge (spp, width) or < 65536 (rows / tile_rows), so for
     // d < 2^15 the product x * d stays below 2^32 and floor(x * M / 2^32) is the exact quotient
     auto magic_for = [](long long d) -> uint32_t {
         return (d <= 1 || d >= 32768) ? 0u : (uint32_t)(0x100000000ULL / (unsigned long long)d + 1ULL);
@@ -777,6 +794,13 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.n_always = ctx->n_always;
     for (int e = 0; e < 8; ++e) kp.always_idx[e] = ctx->always_idx[e];
     kp.fix = (unsigned long long *)d_fix;
+    // the other slot of per-launch state; if the launch that used it last is still running (on another stream), THIS stream waits for
+    // it -- the host does not -- before the counters are cleared
+    ctx->cur = (ctx->cur + 1) % rt_context::kSlots;
+    ctx->d_queue = ctx->q_slots[ctx->cur]; ctx->d_stats = ctx->s_slots[ctx->cur];
+    ctx->ev0 = ctx->e0_slots[ctx->cur]; ctx->ev1 = ctx->e1_slots[ctx->cur];
+    if (ctx->slot_used[ctx->cur]) RT_HIP(hipStreamWaitEvent(stream, ctx->ev1, 0));
+    ctx->slot_used[ctx->cur] = true;
     kp.queue = ctx->d_queue; kp.stats = ctx->d_stats;
 
     if (!(p->flags & RT_FLAG_ACCUMULATE) && npix > 0)
@@ -1041,6 +1065,25 @@ int rt_quantize_device(rt_context *ctx, const double *x, int32_t n, uint64_t *ou
     hipLaunchKernelGGL(rt::quantize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->own_stream, (const double *)dx, (int)n, dq);
     RT_HIP(hipGetLastError());
     RT_HIP(hipMemcpyAsync(out, dq, bytes, hipMemcpyDeviceToHost, ctx->own_stream));
+    RT_HIP(hipStreamSynchronize(ctx->own_stream));
+    return RT_OK;
+}
+
+int rt_unit_accept_device(rt_context *ctx, const uint32_t *words, int32_t n, uint32_t *out_accept, double *out_uniforms)
+{
+    if (!ctx || !words || !out_accept || !out_uniforms || n < 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    const size_t wb = (size_t)n * 3 * sizeof(uint32_t), ab = (size_t)n * sizeof(uint32_t), ub = (size_t)n * 4 * sizeof(double);
+    int rc = ensure(&ctx->d_stage_fix, &ctx->stage_fix_bytes, ub + wb + ab);
+    if (rc) return rc;
+    double *du = (double *)ctx->d_stage_fix;
+    uint32_t *dw = (uint32_t *)(du + 4 * (size_t)n), *da = dw + 3 * (size_t)n;
+    RT_HIP(hipMemcpyAsync(dw, words, wb, hipMemcpyHostToDevice, ctx->own_stream));
+    hipLaunchKernelGGL(rt::unit_accept_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->own_stream, (const uint32_t *)dw, (int)n, da, du);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemcpyAsync(out_accept, da, ab, hipMemcpyDeviceToHost, ctx->own_stream));
+    RT_HIP(hipMemcpyAsync(out_uniforms, du, ub, hipMemcpyDeviceToHost, ctx->own_stream));
     RT_HIP(hipStreamSynchronize(ctx->own_stream));
     return RT_OK;
 }

@@ -83,10 +83,15 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
     return o;
 }
 
-// word -> uniform in [0,1): (w >> 8) * 2^-24 (exact).
-__device__ __forceinline__ double u01(uint32_t w) { return (double)(w >> 8) * (1.0 / 16777216.0); }
-// gen_range(-1.0..1.0) / (-1.0..=1.0): 2u - 1 (exact).
-__device__ __forceinline__ double u11(uint32_t w) { return 2.0 * u01(w) - 1.0; }
+// word -> draw from [0,1) (gen::<f64>()): u = w * 2^-32, all 32 bits of the word (exact in f64).  (Rounds 1-4: (w >> 8) * 2^-24,
+// a leftover of the abandoned f32 plan; the shift is gone and the lattice is 256 times finer for the same Philox work.)
+__device__ __forceinline__ double u01(uint32_t w) { return (double)w * (1.0 / 4294967296.0); }
+// word -> draw from the symmetric ranges gen_range(-1.0..1.0) / (-1.0..=1.0): the word read as a TWO'S-COMPLEMENT integer,
+// x = m * 2^-31 with m = (int32_t)w in [-2^31, 2^31): exact, two instructions (v_cvt_f64_i32, v_mul_f64), and the integer m is what
+// the rejection tests below square -- no bias to subtract first.  (As uniform on its lattice as 2 u01(w) - 1, which is this value
+// for the word with its top bit flipped.)
+__device__ __forceinline__ int32_t u11_int(uint32_t w) { return (int32_t)w; }
+__device__ __forceinline__ double u11(uint32_t w) { return (double)u11_int(w) * (1.0 / 2147483648.0); }
 
 // RT_FLAG_UNIFORM53: a uniform from TWO consecutive words, u = ((w0 << 32 | w1) >> 11) * 2^-53 -- the 53 random bits of
 // rand 0.8.5's gen::<f64>() (main.rs:131-132, materials.rs:96).  k = w0 * 2^21 + (w1 >> 11) < 2^53: both conversions, the
@@ -97,20 +102,41 @@ __device__ __forceinline__ double u01_53(uint32_t w0, uint32_t w1)
 }
 __device__ __forceinline__ double u11_53(uint32_t w0, uint32_t w1) { return 2.0 * u01_53(w0, w1) - 1.0; }
 
-// The reference's rejection tests on such uniforms (vec3.rs:37-45 `length_squared() < 1.0`, vec3.rs:59-68), exactly.
-// u11(w) = m * 2^-23 with the integer m = (w >> 8) - 2^23 in [-2^23, 2^23); m*m needs 46 bits and a sum of three
-// such squares 48, so every f64 product and sum in `x*x + y*y + z*z` is EXACT and the f64 comparison with 1.0 is
-// the integer comparison sum(m^2) < 2^46.  The retry loops run on the integers and convert the accepted draw once.
-__device__ __forceinline__ long long u11_int(uint32_t w) { return (long long)((int32_t)(w >> 8) - 0x800000); }
+// The reference's rejection tests on such uniforms (vec3.rs:37-45 `length_squared() < 1.0`, vec3.rs:59-68), bit for bit, on the
+// integers.  x_i = u11(w_i) = m_i * 2^-31 with |m_i| <= 2^31, so the exact sum of squares is S * 2^-62 with the integer
+// S = sum m_i^2 <= 3 * 2^62 < 2^64 (three v_mad_i64_i32).  The reference evaluates x*x + y*y + z*z in f64, rounding each product
+// and each sum (m_i^2 has up to 62 bits): its value s differs from the exact one by at most 3 * 2^-53 * S * 2^-62 * (1 + 2^-52) < 2^-49
+// (S * 2^-62 <= 3).  Hence
+//     S <  2^62 - 2^32   =>  exact <= 1 - 2^-30  =>  s < 1.0        (accepted, as the reference accepts)
+//     S >= 2^62 + 2^32   =>  exact >= 1 + 2^-30  =>  s > 1.0        (rejected, as the reference rejects)
+// and only in between -- the high dword of S is 2^30 - 1 or 2^30: 1.5e-9 of the tries -- can the roundings decide; there the
+// expression is evaluated in f64 exactly as the reference writes it (vec3.rs:87-89: (x*x + y*y) + z*z, no fused multiply-add).
+// The retry loops run on the integers and convert the accepted draw once.  (Rounds 1-4: a 2^-23 lattice, where every product and
+// sum was exact in f64 and no fallback was needed.)
+__device__ __forceinline__ bool unit_norm_accepts_slow(uint32_t wx, uint32_t wy, uint32_t wz)
+{
+    const double x = u11(wx), y = u11(wy), z = u11(wz);
+    return x * x + y * y + z * z < 1.0;
+}
 __device__ __forceinline__ bool unit_disk_accepts(uint32_t wx, uint32_t wy)
 {
-    const long long x = u11_int(wx), y = u11_int(wy);
-    return (unsigned long long)(x * x + y * y) < (1ull << 46);
+    const int32_t x = u11_int(wx), y = u11_int(wy);
+    const unsigned long long S = (unsigned long long)((long long)x * x) + (unsigned long long)((long long)y * y);
+    const uint32_t hi = (uint32_t)(S >> 32);
+    bool acc = hi < 0x3FFFFFFFu;
+    // (vec3.rs:65 tests Vec3::new(x, y, 0.0).length_squared(): (x*x + y*y) + 0.0*0.0 -- the word 0 gives z = 0.0)
+    if (__builtin_expect(hi - 0x3FFFFFFFu < 2u, 0)) acc = unit_norm_accepts_slow(wx, wy, 0u);
+    return acc;
 }
 __device__ __forceinline__ bool unit_sphere_accepts(uint32_t wx, uint32_t wy, uint32_t wz)
 {
-    const long long x = u11_int(wx), y = u11_int(wy), z = u11_int(wz);
-    return (unsigned long long)(x * x + y * y + z * z) < (1ull << 46);
+    const int32_t x = u11_int(wx), y = u11_int(wy), z = u11_int(wz);
+    const unsigned long long S = (unsigned long long)((long long)x * x) + (unsigned long long)((long long)y * y)
+                                 + (unsigned long long)((long long)z * z);
+    const uint32_t hi = (uint32_t)(S >> 32);
+    bool acc = hi < 0x3FFFFFFFu;
+    if (__builtin_expect(hi - 0x3FFFFFFFu < 2u, 0)) acc = unit_norm_accepts_slow(wx, wy, wz);
+    return acc;
 }
 
 // Contract C5: truncate one radiance channel to the 2^-32 grid, clamped at 2^16 = kSampleClamp (include/rtiow_hip.h,
@@ -420,7 +446,9 @@ __device__ __forceinline__ void grid_row_run(const GridSeg &s, int c0, int c1, f
     const float dl = __builtin_fmaxf(__builtin_fmaf(s.sg, fz, s.alo), s.dmin), dh = __builtin_fminf(__builtin_fmaf(s.sg, fz, s.ahi), s.dmax);
     const float lo = __builtin_fmaf(dl, s.sl, s.xl), hi = __builtin_fmaf(dh, s.sl, s.xh);
     ix0 = min(max((int)__builtin_floorf(lo), c0), c1);
-    nx = min(max((int)__builtin_floorf(hi), c0), c1) - ix0 + 1;
+    // (nx >= 1 by construction: the band always overlaps the piece, dl <= dh, by margins of 6e cells against ~8e-6 cells of rounding --
+    //  but a run of 0 or fewer columns would make the caller's mask shift undefined and the filter unsound, so it is also structural)
+    nx = max(min(max((int)__builtin_floorf(hi), c0), c1) - ix0, 0) + 1;
 }
 
 // (of, df: the ray's origin and direction rounded to f32, o1 = |of|_1 -- shared with make_tube)

@@ -102,6 +102,7 @@ constexpr int kItemBlock = 256;     // pixel-samples a wave reserves per atomic 
 // a quarter of both (1200x675x500: 52.7 -> 51.3 ms; 10k spheres 1920x1080x256: 93.7 -> 91.5 ms).  Smaller launches keep 256: their last
 // blocks are the end-of-launch tail (1200x675x147 is 5 % slower with 1 024).
 constexpr int kItemBlockLarge = 1024;
+static_assert(kItemBlockLarge + 32768 < 65536, "udiv_small: numerators x < d + kItemBlockLarge with d < 2^15 keep x * d < 2^32");
 constexpr int kLargeMinSpp = 147;
 constexpr unsigned long long kLargeMinItems = 1ull << 28;
 constexpr int kRingSlots = 8;       // pixels a block may touch when its sums are kept in LDS: ceil(255 / spp) + 1 <= 8
@@ -117,8 +118,8 @@ __device__ __forceinline__ D3 ld3(const double *p) { return mk(p[0], p[1], p[2])
 // x / d for a launch constant d >= 1 and a numerator with x < d + 65536 and x < 2^31, without a division (a `/`
 // would have the compiler keep one reciprocal per divisor in a VGPR for the whole bounce loop):
 //   d == 1: x;  d >= 2^15: the quotient is 0 or 1;  else floor(x * M / 2^32), M = floor(2^32/d) + 1,
-//   exact because x * (M d - 2^32) <= x d < 2^32: the numerators here are < d + 256 (spp, width) or < 2^16
-//   (rows / tile_rows), so x d < 2^32 for every d < 2^15.
+//   exact because x * (M d - 2^32) <= x d < 2^32: the numerators here are < d + kItemBlockLarge (spp, width) or < 2^16
+//   (rows / tile_rows), so x < 2^15 + 2^10 and x d < 2^32 for every d < 2^15.
 __device__ __forceinline__ uint32_t udiv_small(uint32_t x, uint32_t d, uint32_t magic)
 {
     const uint32_t big = x >= d ? 1u : 0u;
@@ -191,8 +192,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // SMALLGRID (MODE 5 only): the scene's tile grid has at most 64 cells (with the global tiles: a list of <= 64 tiles) --
 // the host picks this instantiation then; it carries neither the large-grid list code nor the scan-every-tile fallback.
 // U53 (RT_FLAG_UNIFORM53): every uniform takes two consecutive Philox words (53 random bits, as rand's gen::<f64>()) instead
-// of one word's 24 bits: same draw order, same runs; the rejection tests run in f64 as the reference writes them (the
-// integer form needs the 2^-23 lattice).  An optional mode: ~2x the Philox work of the retry loops.
+// of one word's 32 bits: same draw order, same runs; the rejection tests run in f64 as the reference writes them (the
+// integer form needs the 2^-31 lattice of single words).  An optional mode: ~2x the Philox work of the retry loops.
 // ITEMS: pixel-samples per work block (kItemBlock, or kItemBlockLarge for launches with enough samples: see rt_api.hip).
 template <int MODE, bool DIAG, bool SMALLGRID = false, bool U53 = false, int ITEMS = 256>
 // second launch bound = waves per SIMD the register allocator must leave room for: the bounce loop
@@ -425,9 +426,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     uint32_t g_ev = 1u;
                     const double u = ((double)i + (U53 ? u01_53(w.x, w.y) : u01(w.x))) / wm1;     // main.rs:131
                     const double v = ((double)j + (U53 ? u01_53(w.z, w.w) : u01(w.y))) / hm1;     // main.rs:132
-                    // vec3.rs:59-68: redraw until x*x + y*y < 1.  x = u11(w) = m * 2^-23 with the integer m = (w >> 8) - 2^23, and
-                    // the f64 sum of squares of such values is EXACT (47 bits), so the reference's f64 comparison is the integer
-                    // comparison m_x^2 + m_y^2 < 2^46: the loop runs on integers, the accepted pair is converted once.
+                    // vec3.rs:59-68: redraw until x*x + y*y < 1.  x = u11(w) = m * 2^-31 with the integer m = w - 2^31: the loop runs
+                    // on the integers (rt_device.hpp, unit_disk_accepts: the reference's f64 comparison, bit for bit), the accepted
+                    // pair is converted once.
                     // Block 0 = (u jitter, v jitter, lens x, lens y); every further block holds TWO tries.
                     uint32_t wx = w.z, wy = w.w;
                     if constexpr (U53) {
@@ -1722,6 +1723,18 @@ __global__ void quantize_kernel(const double *x, int n, unsigned long long *q)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) q[k] = quantize(x[k]);
+}
+
+// known-answer hook: the kernel's own rejection tests and word -> uniform conversions on n triples of Philox words.
+// acc[k] = unit_sphere_accepts(w) | unit_disk_accepts(w.x, w.y) << 1; uni[k] = (u01(w.x), u11(w.x), u11(w.y), u11(w.z))
+__global__ void unit_accept_kernel(const uint32_t *w, int n, uint32_t *acc, double *uni)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) {
+        const uint32_t x = w[3 * k], y = w[3 * k + 1], z = w[3 * k + 2];
+        acc[k] = (unit_sphere_accepts(x, y, z) ? 1u : 0u) | (unit_disk_accepts(x, y) ? 2u : 0u);
+        uni[4 * k] = u01(x); uni[4 * k + 1] = u11(x); uni[4 * k + 2] = u11(y); uni[4 * k + 3] = u11(z);
+    }
 }
 
 } // namespace rt

@@ -187,6 +187,16 @@ class Renderer:
                    "rt_quantize_device")
         return q
 
+    def unit_accept(self, words):
+        """The kernel's own rejection tests and word -> uniform rules on (n, 3) Philox words (known-answer test hook):
+        returns (accept u32 [n]: bit 0 unit sphere, bit 1 unit disk; uniforms f64 [n, 4] = u01(wx), u11(wx), u11(wy), u11(wz))."""
+        w = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, 3)
+        acc = np.zeros(len(w), dtype=np.uint32)
+        uni = np.zeros((len(w), 4), dtype=np.float64)
+        _ffi.check(self._lib.rt_unit_accept_device(self._h, w.ctypes.data_as(C.c_void_p), len(w), acc.ctypes.data_as(C.c_void_p),
+                                                   uni.ctypes.data_as(C.c_void_p)), "rt_unit_accept_device")
+        return acc, uni
+
     def filter_products(self, r1, r2, s, bf16x3=True):
         """Matrix-pipe filter products HB = R1 x S^T, Q = R2 x S^T of scan modes 2/3 (known-answer test
         hook; cross-check build only)."""

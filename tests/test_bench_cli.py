@@ -122,3 +122,17 @@ def test_rmse_helper_on_the_two_oracles():
     cb, rows_j, cpu_sums = bench.cpu_baseline(flat, w, h, spp, target_seconds=0.2, min_rows=10)
     assert len(rows_j) == cpu_sums.shape[0] >= 10 and cb["kind"] == "port" and cb["value"] > 0
     assert np.array_equal(rows_j, np.arange(0, h, rows_j[1] - rows_j[0])[:len(rows_j)])
+
+
+def test_weak_efficiency_is_formed_against_the_committed_single_gpu_line():
+    """At N > 1 the line carries T(--weak-baseline) / T(this run) at equal samples per GPU (SURVEY.md 8(e)), labelled cross-run;
+    no value for a rehearsal on one GPU or for another per-GPU sample count."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_weak_baseline.json")))
+    base = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    spg = base["config"]["samples_per_gpu"]
+    assert spg == 3840 * 2160 * 500 == 7680 * 4320 * 125                    # configs[2] on one GPU = an eighth of configs[4]
+    e = bench.weak_efficiency(base["ms_per_step"] / 0.95, spg, bench.kernel_source_sha(), False)
+    assert abs(e["value"] - 0.95) < 1e-3 and "cross-run" in e["kind"] and e["baseline_source"].startswith("profiles/")
+    assert bench.weak_efficiency(600.0, spg, "x", True)["value"] is None      # rehearsal
+    assert bench.weak_efficiency(600.0, spg // 2, "x", False)["value"] is None

@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size-2 gloo.  Each rank produces its row shard
+"""The N>1 path on CPU: world_size-2 and world_size-8 gloo.  Each rank produces its row shard
 (with the CPU oracle standing in for the GPU kernel -- this is a test), one
 gather brings the exact sums to rank 0, and the reassembled frame must equal
 the single-process frame bit for bit."""
@@ -36,7 +36,7 @@ def _worker(rank, world, port, tile_rows, w, h, spp, out_path):
     parts = []
     for lo in range(0, len(rows), tile_rows):
         tile = rows[lo:lo + tile_rows]
-        fix, _, _ = oracle.render_b(cam, flat, oracle.make_params(w, h, spp, rows=(int(tile[0]), int(tile[-1]) + 1, 1), nthreads=2))
+        fix, _, _ = oracle.render_b(cam, flat, oracle.make_params(w, h, spp, rows=(int(tile[0]), int(tile[-1]) + 1, 1), nthreads=2 if world <= 2 else 1))
         parts.append(fix)
     local = np.concatenate(parts, axis=0) if parts else np.zeros((0, w, 3), dtype=np.uint64)
     full = gather_frame(torch.from_numpy(local.view(np.int64).copy()), h, tile_rows, rank, world)
@@ -51,11 +51,16 @@ def _worker(rank, world, port, tile_rows, w, h, spp, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tile_rows,h", [(4, 18), (5, 23)])      # 23 rows / tiles of 5: ragged last tile
-def test_two_rank_shard_gather_equals_single_process(tmp_path, oracle_mod, book1_flat, tile_rows, h):
+@pytest.mark.parametrize("world,tile_rows,h", [
+    (2, 4, 18), (2, 5, 23),       # 23 rows / tiles of 5: ragged last tile
+    (8, 2, 27),                   # the node's 8 ranks: 14 tiles of 2 rows, the last one ragged (1 row) and on rank 5; ranks 6, 7 own ONE tile,
+                                  # the others two: unequal shards behind equally padded send buffers
+    (8, 1, 11),                   # tiles of one row (bench.py's default): ranks 3..7 own one row, ranks 0..2 two
+])
+def test_shard_gather_equals_single_process(tmp_path, oracle_mod, book1_flat, world, tile_rows, h):
     import torch.multiprocessing as mp
 
-    w, spp, world = 32, 3, 2
+    w, spp = (32, 3) if world == 2 else (16, 2)
     out = str(tmp_path / "full.npy")
     port = _free_port()
     mp.spawn(_worker, args=(world, port, tile_rows, w, h, spp, out), nprocs=world, join=True)

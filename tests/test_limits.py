@@ -28,7 +28,14 @@ def bright_scene(book1_flat, factor=3.0):
 def test_header_states_both_limits():
     hdr = open(os.path.join(ROOT, "include", "rtiow_hip.h")).read()
     assert "#define RT_MAX_SPHERES (1 << 24)" in hdr and "#define RT_SAMPLE_CLAMP 65536.0" in hdr
-    assert "CANNOT wrap while a pixel has received at most 65 536 samples" in hdr
+    assert "CANNOT wrap while a pixel has received FEWER THAN 65 536 samples" in hdr
+
+
+def test_c5_range_is_65535_saturated_samples(oracle_mod):
+    """The largest quantised sample is exactly 2^48: 65 535 of them fit a u64, 65 536 sum to 2^64."""
+    q = int(oracle_mod.load().oracle_b_quantize(float("inf")))
+    assert q == int(oracle_mod.load().oracle_b_quantize(65536.0)) == 1 << 48
+    assert 65535 * q < 2 ** 64 <= 65536 * q
 
 
 def test_c5_clamp_gives_the_references_bytes_for_albedos_above_one(oracle_mod, book1_flat):
@@ -85,6 +92,17 @@ def test_seventy_thousand_spheres_bit_exact(renderer, oracle_mod):
     _, fix, st = renderer.render(low, rt.make_params(w, h, spp, seed=5))
     fb, _, stb = oracle_mod.render_b(oracle_mod.camera_from_host(low), flat, oracle_mod.make_params(w, h, spp, seed=5, nthreads=8))
     assert np.array_equal(fix, fb) and st["rays_traced"] == stb["rays_traced"]
+    # WITHOUT the grid (what a scene of more than ~130 000 filtered spheres gets: no G x G of <= 63 x 63 cells holds it): every wave
+    # scans every tile of the table -- the list_all path with tile numbers >= 2 048 and pool columns >= 2^16
+    os.environ["RTIOW_NO_GRID"] = "1"
+    try:
+        rn = rt.Renderer(0)
+        rn.upload_scene(flat)
+        _, fix_n, st_n = rn.render(low, rt.make_params(w, h, spp, seed=5))
+        rn.close()
+    finally:
+        os.environ.pop("RTIOW_NO_GRID")
+    assert np.array_equal(fix_n, fb) and st_n["rays_traced"] == stb["rays_traced"]
     # the VALU cross-check filter keeps 16-bit candidate lists: it must refuse this scene, not truncate it
     os.environ["RTIOW_SCAN_MODE"] = "1"
     try:

@@ -1,5 +1,5 @@
 """RT_FLAG_UNIFORM53: every uniform from TWO consecutive Philox words (53 random bits, what rand 0.8.5's gen::<f64>() draws
-at main.rs:131-132, materials.rs:96) instead of one word's 24 bits; same draw order.
+at main.rs:131-132, materials.rs:96) instead of one word's 32 bits; same draw order.
 
 CPU: the oracle's word -> uniform rule against Philox words computed independently; the two streams render the same image
 statistically.  GPU: the kernel's 53-bit instantiations against Oracle B, bit for bit (the kernel and the oracle implement the
@@ -16,14 +16,14 @@ def test_oracle_uniforms_are_the_stated_function_of_the_philox_words(oracle_mod)
     words = []
     for e in range(4):
         words += list(oracle_mod.philox((pixel, sample, e, 0), key))
-    u24 = oracle_mod.uniforms(seed, pixel, sample, 16)
-    assert np.array_equal(u24, np.array([(w >> 8) / 2.0 ** 24 for w in words]))
+    u32 = oracle_mod.uniforms(seed, pixel, sample, 16)
+    assert np.array_equal(u32, np.array([w / 2.0 ** 32 for w in words]))          # the default: all 32 bits of one word
     u53 = oracle_mod.uniforms(seed, pixel, sample, 8, uniform53=True)
     want = np.array([(((words[2 * k] << 32) | words[2 * k + 1]) >> 11) / 2.0 ** 53 for k in range(8)])
     assert np.array_equal(u53, want)
     assert ((u53 >= 0) & (u53 < 1)).all() and len(set(u53)) == 8
-    # a 53-bit uniform refines the 24-bit one of its first word: same leading bits
-    assert np.all(np.floor(u53 * 2.0 ** 24) == np.array([words[2 * k] >> 8 for k in range(8)]))
+    # a 53-bit uniform refines the 32-bit one of its first word: same leading bits
+    assert np.all(np.floor(u53 * 2.0 ** 32) == np.array([words[2 * k] for k in range(8)]))
 
 
 def test_oracle_53_bit_stream_renders_the_same_image_statistically(oracle_mod, book1_flat):
