@@ -157,11 +157,11 @@ def self_launch(args):
     return subprocess.call(launch_command(args.gpus, port, sys.argv[1:]), env=env, cwd=ROOT)
 
 
-def time_config(rt, torch, renderer, flat, w, h, spp, launches, stream):
+def time_config(rt, torch, renderer, flat, w, h, spp, launches, stream, flags=0):
     """Kernel time (HIP events) of `launches` whole-frame launches of one configuration."""
     renderer.upload_scene(flat)
     cam = rt.book1_camera(w, h)
-    p = rt.make_params(w, h, spp, seed=1)
+    p = rt.make_params(w, h, spp, seed=1, flags=flags)
     d_fix = torch.zeros((h, w, 3), dtype=torch.int64, device="cuda")
     renderer.render_device(cam, p, d_fix.data_ptr(), stream)      # warm-up
     renderer.last_stats()
@@ -542,6 +542,10 @@ def main():
             others = []
             try:
                 others.append({"config": "configs[1] book-1 1200x675x100", **time_config(rt, torch, renderer, flat, 1200, 675, 100, 10, stream)})
+                # the price of the reference's exact bit count: every draw from TWO Philox words (53 random bits, rand 0.8.5's gen::<f64>())
+                # instead of one word's 32 -- another valid stream, the same frame statistically
+                others.append({"config": "configs[1] book-1 1200x675x100 with RT_FLAG_UNIFORM53 (53-bit draws)",
+                               **time_config(rt, torch, renderer, flat, 1200, 675, 100, 10, stream, flags=rt.RT_FLAG_UNIFORM53)})
                 others.append({"config": "configs[2] book-1 3840x2160x500", **time_config(rt, torch, renderer, flat, 3840, 2160, 500, 2, stream)})
                 tenk = rt.random_scene(1, grid=(-50, 49)).flatten()
                 c4 = time_config(rt, torch, renderer, tenk, 1920, 1080, 256, 2, stream)

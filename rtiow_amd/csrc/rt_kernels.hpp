@@ -854,8 +854,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 // kept iff |H_1| < 2 and |H_2| < 2, i.e. iff bit 30 of BOTH f32 patterns is clear (biased exponent
                 // < 128; infinities and NaNs have it set).  So the look is bit logic: X_bb = AND over the lane's four rays
                 // 8 bb + j of (H_1 | H_2) -- one v_or_b32 and three v_bitop3_b32 (a & (b | c)) per half -- has bit 30
-                // clear iff one of them keeps this sphere, and ONE compare |X_0 & X_1| < 2.0 reads that bit for the
-                // wave-level branch; behind it the two halves are tested as they are.  10 vector instructions of
+                // clear iff one of them keeps this sphere, and one compare per half, |X_bb| < 2.0, reads that bit: the OR of the two
+                // wave masks feeds the wave-level branch, each mask its half of the recording path.  10 vector instructions of
                 // 2.7-4.9 SIMD cycles where max/min-trees took 14 of 4.3-5.4 (tools/valu_cost_table.hip: v_max/v_min*
                 // cost 4.3-5.4 cycles at four waves per SIMD, v_or/v_bitop3 2.7-3.1).
                 auto keeps = [](uint32_t x) -> bool { return __builtin_fabsf(__uint_as_float(x)) < kTubeKeepBelow; };
@@ -869,7 +869,11 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                         for (int j = 1; j < 4; ++j)
                             X[bb] = __builtin_amdgcn_bitop3_b32(X[bb], __float_as_uint(acc[8 * bb + j]), __float_as_uint(acc[8 * bb + 4 + j]), 0xE0);
                     }
-                    if (__builtin_expect(__ballot(keeps(X[0] & X[1])) != 0ull, 0)) {
+                    // one wave-level test per HALF, made once: the branch below is taken when either half keeps something, and the halves'
+                    // masks are what the recording path branches on (round 4 tested X_0 & X_1 here -- one compare -- and each half again behind
+                    // the branch, which two thirds of the looks take: -0.3 % on the book scene, -2 % on the 10k-sphere scene)
+                    const unsigned long long kh[2] = {__ballot(keeps(X[0])), __ballot(keeps(X[1]))};
+                    if (__builtin_expect((kh[0] | kh[1]) != 0ull, 0)) {
                         RT_COUNT(3);
                         int colv = col32;
                         asm volatile("" : "+v"(colv));              // keep the address arithmetic on this side of the branch
@@ -878,7 +882,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                         unsigned int *row = bits_w + rbase;
 #pragma unroll
                         for (int bb = 0; bb < 2; ++bb) {
-                            if (__ballot(keeps(X[bb])) != 0ull) {
+                            if (kh[bb] != 0ull) {
                                 RT_COUNT(4);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
