@@ -517,6 +517,9 @@ struct TubeRay {
 };
 
 // (of, df: the ray's origin and direction rounded to f32; o1 = |of|_1 >= |of|: ray_f32() below)
+// SANITIZE = false: the caller replaces the rows of a ray outside the analysed range itself (tube_rows_keep_nothing) -- the render kernel
+// does it behind ONE wave-level branch together with the lanes that have no ray: eight selects per pass that nearly never select anything
+template <bool SANITIZE = true>
 __device__ __forceinline__ TubeRay make_tube(const float (&of)[3], const float (&df)[3], float o1, float rho)
 {
     TubeRay T;
@@ -540,11 +543,20 @@ __device__ __forceinline__ TubeRay make_tube(const float (&of)[3], const float (
     for (int k = 0; k < 2; ++k)
         T.t[k] = -__builtin_fmaf(T.u[k][2], oz, __builtin_fmaf(T.u[k][1], oy, T.u[k][0] * ox));
     T.sane = (a > 1e-20f) && (a < 1e20f) && (o1 < 1e15f);           // (|o| <= |o|_1 < 1e15: |o|^2 < 1e30, the analysed range)
-    if (!T.sane) {
+    if constexpr (SANITIZE) {
+        if (!T.sane) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) { T.u[k][0] = T.u[k][1] = T.u[k][2] = 0.0f; T.t[k] = 3.0e38f; }
+            for (int k = 0; k < 2; ++k) { T.u[k][0] = T.u[k][1] = T.u[k][2] = 0.0f; T.t[k] = 3.0e38f; }
+        }
     }
     return T;
+}
+// the rows of a ray that keeps NO column: |h| is huge everywhere (a lane without a ray; a ray outside the analysed range, which is tested
+// exactly against the whole list instead)
+__device__ __forceinline__ void tube_rows_keep_nothing(TubeRay &T)
+{
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { T.u[k][0] = T.u[k][1] = T.u[k][2] = 0.0f; T.t[k] = 3.0e38f; }
 }
 __device__ __forceinline__ TubeRay make_tube(D3 o, D3 d, float rho)
 {

@@ -654,13 +654,12 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             // per-ray minimum is taken in LDS on an order-preserving u64 image of the f64 root
             // (ds_min_u64); equal roots resolve to the larger sphere index (ds_max_u32), the same
             // rule as exact_test().  The ring persists across bitmap segments.
-            auto f64_key = [](double x) -> unsigned long long {         // total order of f64 as u64
-                const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-                return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-            };
-            auto key_f64 = [](unsigned long long k) -> double {
-                return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
-            };
+            // The u64 image of a root for ds_min_u64.  Every value that enters is >= t_min > 0, +inf, or a NaN (a root below t_min is not a
+            // root, sphere.rs:29-33; rt_render_device refuses t_min <= 0): for those the f64's own bit pattern IS order-preserving, and a NaN
+            // (0x7FF8..., or 0xFFF8... with the sign set) sorts above +inf, i.e. never wins -- the identity replaces round 1-4's general
+            // total-order transform (a compare, two selects and three bit operations per pooled round and again when the minimum is taken).
+            auto f64_key = [](double x) -> unsigned long long { return (unsigned long long)__double_as_longlong(x); };
+            auto key_f64 = [](unsigned long long k) -> double { return __longlong_as_double((long long)k); };
             auto from_lane_f64 = [](int byte_addr, double x) -> double {
                 const long long b = __double_as_longlong(x);
                 const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(b & 0xFFFFFFFFll));
@@ -676,7 +675,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             // small-grid kernel has no spilled VGPR and measured 0.7 % SLOWER with the seed.)
             constexpr bool SEED = TUBE && !SMALLGRID;
             if constexpr (!SEED) {
-                best_w[lane] = 0xFFF0000000000000ull;                   // f64_key(+inf): closest = infinity
+                best_w[lane] = 0x7FF0000000000000ull;                   // f64_key(+inf): closest = infinity
                 bidx_w[lane] = 0u;                                      // sphere index + 1; 0 = none
             }
             uint32_t pool_n = 0, pool_done = 0;                         // wave-uniform
@@ -711,8 +710,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                         double root = (-half_b - sqrtd) / ra;
                         if (root < t_min) root = (-half_b + sqrtd) / ra;
                         if (!(root < t_min)) {
-                            // (a NaN root maps above +inf and never wins, as in exact_test(); -0 -> +0)
-                            key = f64_key(root + 0.0);
+                            // (a NaN root maps above +inf and never wins, as in exact_test(); root >= t_min > 0 otherwise)
+                            key = f64_key(root);
                             has_root = true;
                         }
                     }
@@ -815,7 +814,14 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 if (scan_mask != 0ull) {
                 float ray_of[3], ray_df[3], ray_o1;                 // (the ray in f32, shared by the filter rows and the footprint)
                 ray_f32(o, d, ray_of, ray_df, ray_o1);
-                const TubeRay T = scan ? make_tube(ray_of, ray_df, ray_o1, P.tube_rho) : no_tube_ray();
+                // (rows of every lane as if it had a ray inside the analysed range; the lanes without one -- none in the steady state: a lane
+                //  whose path ends starts its next sample at once -- and the rays outside it get rows that keep nothing behind ONE wave-level
+                //  branch: 16 selects per pass less)
+                TubeRay T = make_tube<false>(ray_of, ray_df, ray_o1, P.tube_rho);
+                if (!scan) T.sane = true;
+                if (__builtin_expect(__ballot(!scan || !T.sane) != 0ull, 0)) {
+                    if (!scan || !T.sane) tube_rows_keep_nothing(T);
+                }
                 bf16x8 A[4];
                 {
                     uint32_t w[2][8];
@@ -836,7 +842,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i, std::true_type{}); }
                 }
                 if constexpr (SEED) {
-                    best_w[lane] = f64_key(closest);                    // (+inf without a hit: 0xFFF0000000000000)
+                    best_w[lane] = f64_key(closest);                    // (+inf without a hit: 0x7FF0000000000000)
                     bidx_w[lane] = (unsigned)(hit + 1);                 // sphere index + 1; 0 = none
                 }
                 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1436,9 +1442,11 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 if (kind == RT_KIND_LAMBERTIAN) {                                // materials.rs:21-31
                     ndir = nrm + uV;
                     const double eps = 1e-8;
-                    if (__builtin_fabs(ndir.x) < eps && __builtin_fabs(ndir.y) < eps &&
-                        __builtin_fabs(ndir.z) < eps)
-                        ndir = nrm;
+                    // (vec3.rs:111-114 is_near_zero: three compares, and the six selects only behind a wave-level branch that is all but never taken)
+                    const bool near_zero = __builtin_fabs(ndir.x) < eps && __builtin_fabs(ndir.y) < eps && __builtin_fabs(ndir.z) < eps;
+                    if (__builtin_expect(__ballot(near_zero) != 0ull, 0)) {
+                        if (near_zero) ndir = nrm;
+                    }
                 } else if (kind == RT_KIND_METAL) {                              // materials.rs:48-62
                     ndir = uV + sp * param;
                     if (dot(ndir, nrm) <= 0.0) done = true;                      // absorbed: L = 0
