@@ -15,6 +15,9 @@
 
 #include "rtiow_hip.h"
 #include "rt_kernels.hpp"
+#ifdef RTIOW_CROSSCHECK_MODES
+#include "xcheck/rt_xcheck_host_ctx.hpp"
+#endif
 
 namespace {
 
@@ -61,11 +64,7 @@ struct rt_context {
     float grid[8] = {};            // x0, z0, 1/cell, x1, z1, y lo, y hi, pad (rt_device.hpp, grid_cells)
     float scene_scale = 0.0f;      // MODE 5: KParams::scene_scale
 #ifdef RTIOW_CROSSCHECK_MODES
-    float *d_bmat = nullptr;       // [tiles][64] MFMA B operand of the filter
-    float *d_kpt = nullptr;        // [tiles][16] K' per sphere
-    uint4 *d_bmat16 = nullptr;     // [tiles][64] bf16x3 B operand
-    float *d_kpt16 = nullptr;      // [tiles][16] K' for the bf16x3 form
-    uint4 *d_bmatL = nullptr;      // [tiles][2][64] MODE 4 (lifted form) B operands
+    XcheckScene x;                 // device tables of scan modes 2-4 (xcheck/rt_xcheck_host_ctx.hpp)
 #endif
     int n_tiles = 0;
     int n_always = 0;
@@ -169,53 +168,6 @@ void host_split_bf16x3(float x, uint32_t p[3])
     const float r2 = r1 - back(p[1]);
     p[2] = host_bf16_rne(r2);
 }
-#ifdef RTIOW_CROSSCHECK_MODES
-// ---- MODE 4 (lifted form, rt_device.hpp): the per-sphere column C_0..C_10 and its 64 K-slots ----
-// `s == nullptr` (padding) or `never` (a sphere on the always-exact list): a column no ray keeps.
-// Every C_k is computed in f64 from the exact centre/radius and rounded once; C_10 = -K' is
-// rounded UP (K' down), the conservative direction.
-void lifted_column(const rt_sphere *s, bool never, float C[rt::kLiftTerms])
-{
-    for (int k = 0; k < rt::kLiftTerms; ++k) C[k] = 0.0f;
-    C[0] = 1.0f;
-    if (!s || never) { C[10] = rt::kLiftNever; return; }
-    const float kp = filter_kprime(*s, (double)rt::kFilterKU_lifted);
-    if (!(kp > -INFINITY)) { C[10] = rt::kLiftAlways; return; }       // outside the analysed range
-    const double cx = s->center[0], cy = s->center[1], cz = s->center[2];
-    C[1] = (float)cx; C[2] = (float)cy; C[3] = (float)cz;
-    C[4] = (float)(cx * cx); C[5] = (float)(cy * cy); C[6] = (float)(cz * cz);
-    C[7] = (float)(cx * cy); C[8] = (float)(cx * cz); C[9] = (float)(cy * cz);
-    C[10] = -kp;
-}
-// B-side dwords of the slot layout documented at lifted_a_words()
-void lifted_b_words(const float C[rt::kLiftTerms], uint32_t w[32])
-{
-    for (int p = 0; p < 9; ++p) {
-        uint32_t y[3]; host_split_bf16x3(C[1 + p], y);
-        w[3 * p + 0] = y[0] | (y[1] << 16);
-        w[3 * p + 1] = y[0] | (y[2] << 16);
-        w[3 * p + 2] = y[1] | (y[0] << 16);
-    }
-    uint32_t k[3]; host_split_bf16x3(C[10], k);
-    w[27] = rt::kBf16One | (rt::kBf16One << 16);      // C_0 = 1 against the three pieces of R_0
-    w[28] = rt::kBf16One | (k[0] << 16);
-    w[29] = k[1] | (k[2] << 16);
-    w[30] = 0u; w[31] = 0u;
-}
-// one tile (16 columns) of the B table: [m][lane] uint4, lane l = column l&15, K-slots 32m + 8(l>>4)..+7
-void lifted_tile(const float C[16][rt::kLiftTerms], uint4 out[128])
-{
-    for (int c = 0; c < 16; ++c) {
-        uint32_t w[32]; lifted_b_words(C[c], w);
-        for (int m = 0; m < 2; ++m)
-            for (int quad = 0; quad < 4; ++quad) {
-                const uint32_t *q = &w[4 * (4 * m + quad)];
-                out[m * 64 + quad * 16 + c] = make_uint4(q[0], q[1], q[2], q[3]);
-            }
-    }
-}
-
-#endif // RTIOW_CROSSCHECK_MODES
 
 // ---- MODE 5 (tube filter, rt_device.hpp): per-sphere columns and bounds ----
 // Radius floor rho: the rows of a ray are scaled by rho / (rho + e_ray), which keeps the test sound for
@@ -291,9 +243,7 @@ void free_scene(rt_context *ctx)
     (void)hipFree(ctx->d_btube); (void)hipFree(ctx->d_geo_slot); (void)hipFree(ctx->d_slot_orig);
     ctx->d_filt = nullptr; ctx->d_geo = ctx->d_mat = nullptr; ctx->d_btube = nullptr; ctx->d_geo_slot = nullptr; ctx->d_slot_orig = nullptr;
 #ifdef RTIOW_CROSSCHECK_MODES
-    (void)hipFree(ctx->d_bmat); (void)hipFree(ctx->d_kpt); (void)hipFree(ctx->d_bmat16); (void)hipFree(ctx->d_kpt16);
-    (void)hipFree(ctx->d_bmatL);
-    ctx->d_bmat = ctx->d_kpt = nullptr; ctx->d_bmat16 = nullptr; ctx->d_kpt16 = nullptr; ctx->d_bmatL = nullptr;
+    ctx->x.release();
 #endif
     ctx->n_spheres = -1;
 }
@@ -469,6 +419,10 @@ TileLayout tile_layout(const rt_sphere *spheres, int n, const char *never)
     }
     return L;
 }
+
+#ifdef RTIOW_CROSSCHECK_MODES
+#include "xcheck/rt_xcheck_host.inc"       // B operands of scan modes 2-4
+#endif
 
 } // namespace
 
@@ -653,50 +607,7 @@ int rt_upload_scene(rt_context *ctx, const rt_sphere *spheres, int32_t n)
         if (ctx->scan_mode == 1 && !rc) rc = upload_table(&ctx->d_filt, filt.data(), filt.size());
     }
 #ifdef RTIOW_CROSSCHECK_MODES
-    const size_t tcnt = (size_t)n_tiles + 2;
-    if (ctx->scan_mode == 2 || ctx->scan_mode == 3) {
-        std::vector<float> bmat(tcnt * 64, 0.0f), kpt(tcnt * 16, NAN);
-        for (int t = 0; t < n_tiles + 2; ++t)
-            for (int l = 0; l < 64; ++l) {
-                const int i = 16 * t + (l & 15), k = l >> 4;
-                float v = (k == 3) ? 1.0f : 0.0f;                  // padding columns: c = 0
-                if (i < n && k < 3) v = filt[4 * i + k];
-                bmat[(size_t)t * 64 + l] = v;
-            }
-        for (int i = 0; i < n; ++i) kpt[i] = filt[4 * i + 3];      // padding stays NaN: never kept
-        for (int e = 0; e < ctx->n_always; ++e) kpt[ctx->always_idx[e]] = NAN;
-        if (ctx->scan_mode == 2) {
-            if (!rc) rc = upload_table(&ctx->d_bmat, bmat.data(), bmat.size());
-            if (!rc) rc = upload_table(&ctx->d_kpt, kpt.data(), kpt.size());
-        } else {
-            // bf16x3 form: each S value as three bf16 pieces in the element order the A side pairs
-            // with (rt_device.hpp, a_operand_bf16x3), and K' recomputed with that scheme's larger KU
-            std::vector<uint4> bmat16(tcnt * 64, make_uint4(0u, 0u, 0u, 0u));
-            std::vector<float> kpt16(tcnt * 16, NAN);
-            for (size_t e = 0; e < bmat.size(); ++e) {
-                uint32_t y[3]; host_split_bf16x3(bmat[e], y);
-                bmat16[e] = make_uint4(y[0] | (y[1] << 16), y[0] | (y[2] << 16), y[1] | (y[0] << 16), y[2] | (y[1] << 16));
-            }
-            for (int i = 0; i < n; ++i) kpt16[i] = filter_kprime(spheres[i], (double)rt::kFilterKU_bf16x3);
-            for (int e = 0; e < ctx->n_always; ++e) kpt16[ctx->always_idx[e]] = NAN;
-            if (!rc) rc = upload_table(&ctx->d_bmat16, bmat16.data(), bmat16.size());
-            if (!rc) rc = upload_table(&ctx->d_kpt16, kpt16.data(), kpt16.size());
-        }
-    }
-    if (ctx->scan_mode == 4) {
-        std::vector<uint4> bmatL(tcnt * 128);
-        std::vector<char> never(n > 0 ? n : 1, 0);
-        for (int e = 0; e < ctx->n_always; ++e) never[ctx->always_idx[e]] = 1;
-        for (size_t t = 0; t < tcnt; ++t) {
-            float C[16][rt::kLiftTerms];
-            for (int c = 0; c < 16; ++c) {
-                const long i = 16 * (long)t + c;
-                lifted_column(i < n ? &spheres[i] : nullptr, i < n && never[i], C[c]);
-            }
-            lifted_tile(C, &bmatL[t * 128]);
-        }
-        if (!rc) rc = upload_table(&ctx->d_bmatL, bmatL.data(), bmatL.size());
-    }
+    if (!rc) rc = xcheck_upload_tables(ctx, spheres, n, n_tiles, filt);
 #endif
     if (!rc) rc = upload_table(&ctx->d_geo, geo.data(), geo.size());
     if (!rc) rc = upload_table(&ctx->d_mat, mat.data(), mat.size());
@@ -781,8 +692,8 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     kp.filt = ctx->d_filt; kp.geo = ctx->d_geo; kp.mat = ctx->d_mat;
     kp.n_tiles = ctx->n_tiles;
 #ifdef RTIOW_CROSSCHECK_MODES
-    kp.bmat = ctx->d_bmat; kp.kpt = ctx->d_kpt;
-    kp.bmat16 = ctx->d_bmat16; kp.kpt16 = ctx->d_kpt16; kp.bmatL = ctx->d_bmatL;
+    kp.x.bmat = ctx->x.d_bmat; kp.x.kpt = ctx->x.d_kpt;
+    kp.x.bmat16 = ctx->x.d_bmat16; kp.x.kpt16 = ctx->x.d_kpt16; kp.x.bmatL = ctx->x.d_bmatL;
 #endif
     kp.btube = ctx->d_btube; kp.tube_rho = ctx->tube_rho;
     kp.geo_slot = ctx->d_geo_slot; kp.slot_orig = ctx->d_slot_orig;
@@ -1089,58 +1000,8 @@ int rt_unit_accept_device(rt_context *ctx, const uint32_t *words, int32_t n, uin
 }
 
 #ifdef RTIOW_CROSSCHECK_MODES
-int rt_filter_products_device(rt_context *ctx, const float *r1, const float *r2, const float *s,
-                               int32_t bf16x3, float *out_hb, float *out_q)
-{
-    if (!ctx || !r1 || !r2 || !s || !out_hb || !out_q) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
-    RT_HIP(hipSetDevice(ctx->device));
-    const size_t in_f = 64 * 4 * 2 + 16 * 4, out_f = 64 * 16 * 2;
-    int rc = ensure(&ctx->d_stage_fix, &ctx->stage_fix_bytes, (in_f + out_f) * sizeof(float));
-    if (rc) return rc;
-    float *d = (float *)ctx->d_stage_fix;
-    float *d_r1 = d, *d_r2 = d + 256, *d_s = d + 512, *d_hb = d + 576, *d_q = d + 576 + 1024;
-    RT_HIP(hipMemcpyAsync(d_r1, r1, 256 * 4, hipMemcpyHostToDevice, ctx->own_stream));
-    RT_HIP(hipMemcpyAsync(d_r2, r2, 256 * 4, hipMemcpyHostToDevice, ctx->own_stream));
-    RT_HIP(hipMemcpyAsync(d_s, s, 64 * 4, hipMemcpyHostToDevice, ctx->own_stream));
-    hipLaunchKernelGGL(rt::filter_products_kernel, dim3(1), dim3(64), 0, ctx->own_stream,
-                       (const float *)d_r1, (const float *)d_r2, (const float *)d_s, (int)bf16x3, d_hb, d_q);
-    RT_HIP(hipGetLastError());
-    RT_HIP(hipMemcpyAsync(out_hb, d_hb, 1024 * 4, hipMemcpyDeviceToHost, ctx->own_stream));
-    RT_HIP(hipMemcpyAsync(out_q, d_q, 1024 * 4, hipMemcpyDeviceToHost, ctx->own_stream));
-    RT_HIP(hipStreamSynchronize(ctx->own_stream));
-    return RT_OK;
-}
-
-int rt_filter_lifted_device(rt_context *ctx, const double *o, const double *d, const rt_sphere *spheres16,
-                            float *out_D, float *out_R, float *out_C)
-{
-    if (!ctx || !o || !d || !spheres16 || !out_D || !out_R || !out_C) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
-    RT_HIP(hipSetDevice(ctx->device));
-    float C[16][rt::kLiftTerms];
-    for (int c = 0; c < 16; ++c) lifted_column(&spheres16[c], false, C[c]);
-    memcpy(out_C, C, sizeof(C));
-    uint4 tile[128];
-    lifted_tile(C, tile);
-    const size_t in_b = 64 * 3 * 8 * 2 + sizeof(tile), out_b = (64 * 16 + 64 * rt::kLiftTerms) * 4;
-    int rc = ensure(&ctx->d_stage_fix, &ctx->stage_fix_bytes, in_b + out_b);
-    if (rc) return rc;
-    char *base = (char *)ctx->d_stage_fix;
-    double *d_o = (double *)base, *d_d = d_o + 192;
-    uint4 *d_tile = (uint4 *)(base + 3072);
-    float *d_D = (float *)(base + 3072 + sizeof(tile)), *d_R = d_D + 1024;
-    RT_HIP(hipMemcpyAsync(d_o, o, 1536, hipMemcpyHostToDevice, ctx->own_stream));
-    RT_HIP(hipMemcpyAsync(d_d, d, 1536, hipMemcpyHostToDevice, ctx->own_stream));
-    RT_HIP(hipMemcpyAsync(d_tile, tile, sizeof(tile), hipMemcpyHostToDevice, ctx->own_stream));
-    hipLaunchKernelGGL(rt::lifted_products_kernel, dim3(1), dim3(64), 0, ctx->own_stream,
-                       (const double *)d_o, (const double *)d_d, (const uint4 *)d_tile, d_D, d_R);
-    RT_HIP(hipGetLastError());
-    RT_HIP(hipMemcpyAsync(out_D, d_D, 1024 * 4, hipMemcpyDeviceToHost, ctx->own_stream));
-    RT_HIP(hipMemcpyAsync(out_R, d_R, 64 * rt::kLiftTerms * 4, hipMemcpyDeviceToHost, ctx->own_stream));
-    RT_HIP(hipStreamSynchronize(ctx->own_stream));
-    return RT_OK;
-}
-
-#endif // RTIOW_CROSSCHECK_MODES
+#include "xcheck/rt_xcheck_hooks.inc"      // rt_filter_products_device, rt_filter_lifted_device
+#endif
 
 int rt_tube_tile_host(const rt_sphere *spheres32, uint32_t *out_words, float *out_bound, float *out_rho)
 {

@@ -31,6 +31,10 @@
 //     ~3 x 64-byte memory-side requests per 256 samples).
 #pragma once
 #include "rt_device.hpp"
+#include "rt_diag.hpp"
+#ifdef RTIOW_CROSSCHECK_MODES
+#include "xcheck/rt_xcheck_params.hpp"
+#endif
 #include <type_traits>
 
 #ifndef RT_GROUP_SKIP
@@ -65,11 +69,7 @@ struct KParams {
     uint32_t pad_magic;
     const float *filt;         // [n][4]  f32 filter record (cx, cy, cz, K')
 #ifdef RTIOW_CROSSCHECK_MODES
-    const float *bmat;         // [tiles][64] MFMA B operand: lane l -> S[k=l>>4][sphere 16t+(l&15)], S=(cx,cy,cz,1)
-    const float *kpt;          // [tiles][16] K' per sphere (NaN: never kept by the filter)
-    const uint4 *bmat16;       // [tiles][64] bf16x3 B operand: 8 bf16 (y1,y2,y1,y3,y2,y1,y3,y2) of S[k][sphere]
-    const float *kpt16;        // [tiles][16] K' for the bf16x3 form (larger KU)
-    const uint4 *bmatL;        // [tiles][2][64] MODE 4 B operands: the 64 K-slots of the lifted form (rt_device.hpp)
+    KXcheckTables x;           // the B operands of scan modes 2-4 (xcheck/rt_xcheck_params.hpp)
 #endif
     const uint4 *btube;        // [tiles/2 + 1][64] MODE 5 B operands: 32 spheres x 16 K-slots, each column scaled by 2 / its bound (rt_device.hpp)
     float tube_rho;            // MODE 5 radius floor
@@ -128,41 +128,6 @@ __device__ __forceinline__ uint32_t udiv_small(uint32_t x, uint32_t d, uint32_t 
 }
 
 
-#ifdef RT_LDS_CONFLICTS
-// Diagnostic build only (tools/lds_conflicts.py): a software model of the LDS bank serialisation of ONE wave-level LDS
-// instruction, per MI355X_MICROARCH.md section LDS: the lanes are served in fixed groups (4-byte accesses: 2 x 32 lanes, 32
-// banks; 8-byte stores and atomics: 4 x 16 lanes, 16 bank pairs; 8-byte loads: 2 x 32 lanes, 32 bank pairs), identical
-// addresses broadcast for a load, and every further distinct address on a busy bank costs one more LDS cycle; an atomic
-// serialises same-address lanes too.  Returns the EXTRA cycles of the instruction (what SQ_LDS_BANK_CONFLICT counts), wave-uniform.
-template <int BYTES, bool ATOMIC, bool LOAD64 = false>
-__device__ __noinline__ uint32_t lds_extra_cycles(uint32_t byte_addr, bool active)
-{
-    constexpr int G = (BYTES == 8 && !LOAD64) ? 16 : 32;            // lanes per group
-    const int lane = threadIdx.x & 63;
-    const unsigned long long m = __ballot(active);
-    const uint32_t unit = byte_addr / (uint32_t)BYTES;              // address in access units
-    const uint32_t bank = unit % (uint32_t)G;                       // (32 dword banks = 16 or 32 units of this size: one unit per lane of a group)
-    bool first = active;                                            // the first lane of its group with this address
-    for (int k = 0; k < 64; ++k) {
-        const uint32_t uk = (uint32_t)__builtin_amdgcn_readlane((int)unit, k);
-        if (((m >> k) & 1ull) && k < lane && k / G == lane / G && uk == unit) first = false;
-    }
-    const unsigned long long counted = ATOMIC ? m : __ballot(first);
-    uint32_t cnt = 0;                                               // accesses the bank of this lane has to serve one after the other
-    for (int k = 0; k < 64; ++k) {
-        const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)bank, k);
-        if (((counted >> k) & 1ull) && k / G == lane / G && bk == bank) cnt++;
-    }
-    if (!active) cnt = 0;
-    uint32_t extra = 0;
-    for (int g = 0; g < 64 / G; ++g) {
-        uint32_t mx = 0;
-        for (int k = g * G; k < (g + 1) * G; ++k) mx = max(mx, (uint32_t)__builtin_amdgcn_readlane((int)cnt, k));
-        extra += mx > 1u ? mx - 1u : 0u;
-    }
-    return extra;
-}
-#endif
 
 // MODE 0: every sphere goes through the exact test (validation mode, RT_FLAG_NO_FILTER):
 //         same results by construction of the filter.
@@ -298,46 +263,13 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
         __builtin_amdgcn_wave_barrier();
     };
 
-#ifdef RT_PHASE_STAMPS
-    // Diagnostic build only (never the shipped library): wave-time spent per phase, summed
-    // into stats[8..15].  The stamps serialise the phases; read the SHARES, not the total.
-    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
-#define RT_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); \
-                         __builtin_amdgcn_s_waitcnt(0); ph[k] += tn_ - tprev; tprev = tn_; } while (0)
-#define RT_COUNT(k) do { } while (0)
-#elif defined(RT_EXIT_TIMES)
-    const unsigned long long t_wave_start = __builtin_amdgcn_s_memrealtime();
-#define RT_STAMP(k) do { } while (0)
-#define RT_COUNT(k) do { } while (0)
-#elif defined(RT_BLOCK_COUNTS)
-    // Diagnostic build only: wave-level execution counts of the main blocks, into stats[8..15].
-    __shared__ unsigned int s_cnt[kBlock / 64][8];
-    if ((tid & 63) < 8) s_cnt[tid >> 6][tid & 7] = 0u;
-#define RT_STAMP(k) do { } while (0)
-#define RT_COUNT(k) do { if ((int)(tid & 63) == (int)__builtin_ctzll(__ballot(true))) s_cnt[tid >> 6][k] += 1u; } while (0)
-#define RT_COUNT_N(k, n) do { if ((int)(tid & 63) == (int)__builtin_ctzll(__ballot(true))) s_cnt[tid >> 6][k] += (unsigned)(n); } while (0)
-#elif defined(RT_LDS_CONFLICTS)
-    // Diagnostic build only: modelled extra LDS cycles per site, into stats[8..15] (see lds_extra_cycles above):
-    // 0 recording ds_or, 1 block-sum ds_add_u64, 2 pool ds_min_u64, 3 pool ds_max_u32 + reset, 4 ds_bpermute of the pool,
-    // 5 bitmap / tile-list reads of the enumeration, 6 sample-queue reads, 7 pool ring + per-ray result reads
-    unsigned long long lds_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define RT_STAMP(k) do { } while (0)
-#define RT_COUNT(k) do { } while (0)
-#define RT_LDS(site, BYTES, ATOMIC, LOAD64, ptr, active) do { lds_x[site] += lds_extra_cycles<BYTES, ATOMIC, LOAD64>( \
-        (uint32_t)(uintptr_t)(const void __attribute__((address_space(3))) *)(ptr), (active)); } while (0)
-#define RT_LDS_N(site, n, BYTES, ATOMIC, LOAD64, byte_addr, active) do { lds_x[site] += (unsigned long long)(n) * \
-        lds_extra_cycles<BYTES, ATOMIC, LOAD64>((uint32_t)(byte_addr), (active)); } while (0)
-#else
-#define RT_STAMP(k) do { } while (0)
-#define RT_COUNT(k) do { } while (0)
-#endif
-#ifndef RT_COUNT_N
-#define RT_COUNT_N(k, n) do { } while (0)
-#endif
-#ifndef RT_LDS
-#define RT_LDS(site, BYTES, ATOMIC, LOAD64, ptr, active) do { } while (0)
-#define RT_LDS_N(site, n, BYTES, ATOMIC, LOAD64, byte_addr, active) do { } while (0)
-#endif
+    RT_DIAG_DECLARE();              // (rt_diag.hpp: nothing in the shipped library)
+    // One pass of the bounce loop = five phases, marked "==== PHASE n" below; the helpers they call are the lambdas defined next to their
+    // data (flush_ring, exact_test_g, pool_round, enumerate, finish_pool, look_tube, do_tile, build_list).  The phases themselves stay
+    // INLINE: wrapped into named lambdas (round 5 tried it: take_samples / start_camera_rays / shade / accumulate_finished) the same code
+    // compiles to a different register allocation at this kernel's zero-headroom budget (128 VGPRs) -- one wrapper alone puts 20 scratch
+    // instructions into the small-grid kernel, all four cost +0.3 % frame time (profiles/r05_experiments.txt 8) -- so the structure is in
+    // the comments and tools/isa_fingerprint.py guards refactorings (the machine code of this file's kernels before = after).
     for (;;) {
         // Wave priorities through a pass (s_setprio): 1 from here -- taking samples, refill, camera rays, then the filter rows, the ground
         // test and the tile list --, 3 in the tile loop (the matrix pipe is fed sooner and the other waves' vector work fills the time
@@ -347,6 +279,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
         // priorities at all +1.1 %; a dozen other assignments within 0.3 % of this one or slower (profiles/r04_experiments.txt 30).
         __builtin_amdgcn_s_setprio(1);
         RT_COUNT(0);
+        // ==== PHASE 1: take_samples ============================================================================================
         // ---- (a) lanes without a path take the next camera rays of the wave's queue -------------------------
         // Starting a sample (item -> pixel, Philox, lens rejection, the f64 camera arithmetic: ~340 vector
         // instructions) used to run in every pass with only the ~38 % of lanes whose path had just ended.  Now the
@@ -406,9 +339,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     }
                 }
                 const uint32_t n_gen = min(64u, blk_end - blk_next);
-#if !defined(RT_COUNT_ROWS) && !defined(RT_COUNT_ENUM)
-                RT_COUNT(1);
-#endif
+                RT_COUNT_MAIN(1);
                 if ((uint32_t)lane < n_gen) {
                     // item blk_next + lane of the block: sample blk_s0 + that of pixel blk_pix0, carried over into the next pixels
                     const uint32_t s_rel = blk_s0 + blk_next + (uint32_t)lane;
@@ -461,11 +392,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 RT_STAMP(8);
             }
             const uint32_t r = rank_below(m);
-#ifdef RT_LDS_CONFLICTS
-            { const bool take_ = want && r < q_count; const uint32_t e_ = take_ ? q_head + r : 0u;
-              RT_LDS(6, 8, false, true, &quv_w[e_], take_); RT_LDS(6, 8, false, true, &quv_w[64 + e_], take_);
-              for (int c_ = 0; c_ < 5; ++c_) RT_LDS(6, 4, false, false, &qid_w[c_ * 64 + e_], take_); }
-#endif
+            RT_LDS_QUEUE_READS(want && r < q_count, q_head + r);
             if (want && r < q_count) {
                 const uint32_t e = q_head + r;
                 cam_u = quv_w[0 * 64 + e]; cam_v = quv_w[1 * 64 + e];
@@ -483,6 +410,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             q_head += took; q_count -= took;
         }
         RT_STAMP(0);
+        // ==== PHASE 2: start_camera_rays =======================================================================================
         if (fresh) {                                                // camera.rs:47-54
             double lx = u11(lens_wx), ly = u11(lens_wy);
             if constexpr (U53) {                                    // the accepted unit-disk try is the last block the start drew
@@ -507,6 +435,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
         // DIAG: rays traced per bounce index (0 = camera ray), per wave in LDS, flushed at exit
         if (DIAG && alive) atomicAdd(&s_live[tid >> 6][min(P.max_depth - depth, 63)], 1u);
 
+        // ==== PHASE 3: scan (filter rows, tile list, tile loop, enumeration, pooled exact tests) ===============================
         // ---- (d) HittableList::hit, mod.rs:54-70 -------------------------------
         double closest = __builtin_inf();
         int hit = -1;
@@ -578,72 +507,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             unsigned int *bits_w = &s_bits[wave][0];                // [word][ray]
             unsigned int *sum_w = &s_sum[TUBE ? 0 : wave * 64];         // (MODE 5 has no summary words)
 #ifdef RTIOW_CROSSCHECK_MODES
-            // Results of half a tile: Dv[g][i] belongs to ray 16(2h+g) + 4 quad + i and sphere
-            // 16 t + col; it is kept iff Dv >= kp.  Hits are rare, so the eight values are first
-            // folded into one maximum and one wave-level branch.
-            auto check_half = [&](int h, const float (&Dv)[2][4], float kp, int trel) {
-                const float m01 = __builtin_fmaxf(__builtin_fmaxf(Dv[0][0], Dv[0][1]), Dv[0][2]);
-                const float m02 = __builtin_fmaxf(__builtin_fmaxf(m01, Dv[0][3]), Dv[1][0]);
-                const float m03 = __builtin_fmaxf(__builtin_fmaxf(m02, Dv[1][1]), Dv[1][2]);
-                const float mall = __builtin_fmaxf(m03, Dv[1][3]);
-                if (__builtin_expect(__ballot(mall >= kp) != 0ull, 0)) {
-                    RT_COUNT(3);
-                    const unsigned bit = 1u << ((trel & 1) * 16 + col);
-                    const unsigned wbit = 1u << (trel >> 1);
-                    unsigned int *row = bits_w + (trel >> 1) * 64;
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        const float mG = __builtin_fmaxf(__builtin_fmaxf(Dv[g][0], Dv[g][1]), __builtin_fmaxf(Dv[g][2], Dv[g][3]));
-                        if (__ballot(mG >= kp) != 0ull) {
-                            RT_COUNT(4);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)             // (a lane without a ray can land here
-                                if (Dv[g][i] >= kp) {               //  only via an always-kept column; harmless)
-                                    const int ray = 16 * (2 * h + g) + 4 * quad + i;
-                                    atomicOr(&row[ray], bit);
-                                    atomicOr(&sum_w[ray], wbit);
-                                }
-                        }
-                    }
-                }
-            };
-            // MODE 4: kept iff Dv >= 0.  Sign tests on the bit patterns (an exact zero cannot occur
-            // for a sphere the reference can hit: the slack kappa S is strictly positive), so the
-            // maxima are integer v_max3 with no NaN canonicalisation in front.
-            auto check_sign_half = [&](int h, const float (&Dv)[2][4], int trel) {
-                int iv[2][4];
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) iv[g][i] = __float_as_int(Dv[g][i]);
-                const int m0 = max(max(iv[0][0], iv[0][1]), iv[0][2]);
-                const int m1 = max(max(m0, iv[0][3]), iv[1][0]);
-                const int m2 = max(max(m1, iv[1][1]), iv[1][2]);
-                const int mall = max(m2, iv[1][3]);
-                if (__builtin_expect(__ballot(mall >= 0) != 0ull, 0)) {
-                    RT_COUNT(3);
-                    int colv = col;
-                    asm volatile("" : "+v"(colv));                  // keep the address arithmetic on this side of the branch
-                    const unsigned bit = 1u << ((trel & 1) * 16 + colv);
-                    const unsigned wbit = 1u << (trel >> 1);
-                    unsigned int *row = bits_w + (trel >> 1) * 64;
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        const int mG = max(max(iv[g][0], iv[g][1]), max(iv[g][2], iv[g][3]));
-                        if (__ballot(mG >= 0) != 0ull) {
-                            RT_COUNT(4);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                if (iv[g][i] >= 0) {
-                                    const int ray = 16 * (2 * h + g) + 4 * quad + i;
-                                    atomicOr(&row[ray], bit);
-                                    atomicOr(&sum_w[ray], wbit);
-                                }
-                        }
-                    }
-                }
-            };
-#endif // RTIOW_CROSSCHECK_MODES
+#include "xcheck/rt_xcheck_looks.inc"      // check_half, check_sign_half: the looks of modes 2-4
+#endif
             // ---- candidates -> exact tests, pooled over the wave -------------------------
             // A ray has 1.1 candidates on average but the longest list in a wave has 5-6, and the
             // exact test is ~80 f64 instructions: testing list entry k of every lane together would
@@ -730,9 +595,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 if (has_root && old > key) bidx_w[r] = 0u;
                 __builtin_amdgcn_wave_barrier();
                 RT_LDS(7, 8, false, true, &best_w[r], has_root);
-#ifdef RT_LDS_CONFLICTS
-                { const bool eq_ = has_root && best_w[r] == key; RT_LDS(3, 4, true, false, &bidx_w[r], eq_); }
-#endif
+                RT_LDS_POOL_TIE(has_root, r, key);
                 if (has_root && best_w[r] == key) atomicMax(&bidx_w[r], (unsigned)idx + 1u);
                 __builtin_amdgcn_wave_barrier();
                 pool_done = min(pool_done + 64u, pool_n);
@@ -755,18 +618,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     const bool has = (summary | word) != 0u;
                     const unsigned long long m = __ballot(has);
                     if (m == 0ull) break;
-#ifdef RT_COUNT_ENUM
-                    RT_COUNT(1);
-                    RT_COUNT_N(6, __popcll(m));
-#endif
-#ifdef RT_LDS_CONFLICTS
-                    if constexpr (TUBE) {
-                        const bool need_ = has && word == 0u;
-                        const int w_ = need_ ? __builtin_ctz(summary) : 0;
-                        RT_LDS(5, 4, false, false, &bits_w[w_ * 64 + lane], need_);
-                        if (SMALLGRID || !list_all) RT_LDS(5, 4, false, false, &bits_w[(kSeg / 2) * 64 + seg0 + w_], need_);
-                    }
-#endif
+                    RT_COUNT_ENUM_TRIP(m);
+                    RT_LDS_ENUM_READS(has, word, summary, seg0);
                     if (has) {
                         if (word == 0u) {
                             const int w = __builtin_ctz(summary);
@@ -999,9 +852,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                             __builtin_amdgcn_wave_barrier();
                             // row by row: the columns of the part of the clipped piece that lies in the row's band (grid_row_run)
                             for (int k = 0; __any(k < nz); ++k) {
-#ifdef RT_COUNT_ROWS
-                                RT_COUNT(1);
-#endif
+                                RT_COUNT_ROWS_TRIP(1);
                                 if (k < nz) {
                                     int rx0, rnx;                                           // 1 <= rnx, rnx + rx0 <= grid_dim <= 32 or 63
                                     grid_row_run(seg, ix0, ix0 + nx - 1, (float)(iz0 + k), rx0, rnx);
@@ -1022,9 +873,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                                 int pos = P.n_global + upto - mine;
                                 const int row0 = P.n_global + lane * P.grid_dim;
                                 while (__any(mw != (W)0)) {
-#ifdef RT_COUNT_ROWS
-                                    RT_COUNT(6);
-#endif
+                                    RT_COUNT_ROWS_TRIP(6);
                                     if (mw != (W)0) {
                                         const int bpos = sizeof(W) == 8 ? __builtin_ctzll(mw) : __builtin_ctz((unsigned)mw);
                                         unsigned gm = 0u;
@@ -1114,154 +963,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 }   // scan_mask != 0
             }
 #ifdef RTIOW_CROSSCHECK_MODES
-            else if constexpr (LIFTED) {
-                const LiftedRay L = alive ? make_lifted(o, d) : no_lifted_ray();
-                bf16x8 A[4][2];
-                {
-                    uint32_t w[32];
-                    lifted_a_words(L, w);
-                    lifted_stage_operands(reinterpret_cast<uint4 *>(bits_w), lane, w, A);
-                }
-                if (alive) {
-                    for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e], std::false_type{}); }
-                    // outside the analysed range: everything is tested exactly
-                    if (!L.sane) {
-                        closest = __builtin_inf(); hit = -1;
-                        for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i, std::true_type{}); }
-                    }
-                }
-                // B operands: 2 KB per tile, lane l reads 16 bytes at 16 l of each half; a raw buffer
-                // load takes the lane part from a VGPR that never changes and the tile part from
-                // an SGPR: no vector address arithmetic in the loop
-                const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<uint4 *>(P.bmatL), 0, (nt + 2) * 2048, 0x00020000);
-                const int voff = lane * 16;
-                auto load_b = [&](int tile, int m) -> bf16x8 {
-                    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, voff, (2 * tile + m) * 1024, 0));
-                };
-                RT_STAMP(5);
-                for (int seg0 = 0; seg0 < nt; seg0 += kSegTiles) {
-                    const int seg_n = min(kSegTiles, nt - seg0);
-                    const int nwords = seg_n >> 1;
-                    for (int w = 0; w < nwords; ++w) bits_w[w * 64 + lane] = 0u;
-                    s_sum[tid] = 0u;
-                    __builtin_amdgcn_wave_barrier();
-                    // one tile: 2 ray-group pairs x (2 chained MFMAs each), sign look after each pair;
-                    // two ray groups interleaved so a chained MFMA never waits on its own input
-                    auto do_tile = [&](int tr, const bf16x8 &b0, const bf16x8 &b1) {
-                        RT_COUNT(7);
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2 * h][0], b0, zero, 0, 0, 0);
-                            f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2 * h + 1][0], b0, zero, 0, 0, 0);
-                            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2 * h][1], b1, acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2 * h + 1][1], b1, acc1, 0, 0, 0);
-                            const float Dv[2][4] = {{acc0[0], acc0[1], acc0[2], acc0[3]}, {acc1[0], acc1[1], acc1[2], acc1[3]}};
-                            check_sign_half(h, Dv, tr);
-                        }
-                    };
-                    // B operands ping-pong between two register sets, each fetched a tile ahead
-                    bf16x8 p0 = load_b(seg0, 0), p1 = load_b(seg0, 1), q0, q1;
-                    for (int tr = 0; tr < seg_n; tr += 2) {             // seg_n is even
-                        q0 = load_b(seg0 + tr + 1, 0); q1 = load_b(seg0 + tr + 1, 1);
-                        do_tile(tr, p0, p1);
-                        p0 = load_b(seg0 + tr + 2, 0); p1 = load_b(seg0 + tr + 2, 1);
-                        do_tile(tr + 1, q0, q1);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    RT_STAMP(6);
-                    enumerate(seg0);
-                }
-                finish_pool();
-            } else {
-            RayFilter f;
-            if (alive) {
-                f = make_filter<MODE == 3>(o, d);
-            } else {                                    // no ray: D'' hugely negative, never kept
-                f.gx = f.gy = f.gz = f.h0 = 0.0f; f.px = f.py = f.pz = 0.0f; f.o2 = 1e30f; f.sane = true;
-            }
-            float *rop = &s_rayop[wave][0][0];
-            rop[0 * kRowPad + lane] = -f.gx; rop[1 * kRowPad + lane] = -f.gy;
-            rop[2 * kRowPad + lane] = -f.gz; rop[3 * kRowPad + lane] = f.h0;
-            rop[4 * kRowPad + lane] = f.px;  rop[5 * kRowPad + lane] = f.py;
-            rop[6 * kRowPad + lane] = f.pz;  rop[7 * kRowPad + lane] = f.o2;
-            __builtin_amdgcn_wave_barrier();            // LDS ops of one wave execute in order
-            // A operands: lane l holds R[ray 16G + (l&15)][k = l>>4]
-            typedef typename std::conditional<MODE == 3, bf16x8, float>::type aop_t;
-            typedef typename std::conditional<MODE == 3, uint4, float>::type bop_t;
-            aop_t A_hb[4], A_q[4];
-#pragma unroll
-            for (int G = 0; G < 4; ++G) {
-                const float vh = rop[quad * kRowPad + 16 * G + col];
-                const float vq = rop[(4 + quad) * kRowPad + 16 * G + col];
-                if constexpr (MODE == 3) { A_hb[G] = a_operand_bf16x3(vh); A_q[G] = a_operand_bf16x3(vq); }
-                else { A_hb[G] = vh; A_q[G] = vq; }
-            }
-            const bop_t *btab;
-            const float *ktab;
-            if constexpr (MODE == 3) { btab = P.bmat16; ktab = P.kpt16; } else { btab = P.bmat; ktab = P.kpt; }
-            // the 4 MFMAs of half a tile: ray groups 2h, 2h+1 x {HB, Q}
-            auto mfma_half = [&](int h, bop_t bw, f32x4 (&hb)[2], f32x4 (&q)[2]) {
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    if constexpr (MODE == 3) {
-                        const bf16x8 bb = __builtin_bit_cast(bf16x8, bw);
-                        hb[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_hb[2 * h + g], bb, zero, 0, 0, 0);
-                        q[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_q[2 * h + g], bb, zero, 0, 0, 0);
-                    } else {
-                        hb[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_hb[2 * h + g], bw, zero, 0, 0, 0);
-                        q[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_q[2 * h + g], bw, zero, 0, 0, 0);
-                    }
-                }
-            };
-            // D'' = hb^2 - q for the 8 results per lane of half a tile
-            auto look_half = [&](int h, const f32x4 (&hb)[2], const f32x4 (&q)[2], float kp, int trel) {
-                float Dv[2][4];
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) Dv[g][i] = __builtin_fmaf(hb[g][i], hb[g][i], -q[g][i]);
-                check_half(h, Dv, kp, trel);
-            };
-            if (alive) {
-                for (int e = 0; e < P.n_always; ++e) { if (DIAG) n_cand++; exact_test(P.always_idx[e], std::false_type{}); }
-                // outside the analysed range: everything is tested exactly
-                if (!f.sane) {
-                    closest = __builtin_inf(); hit = -1;
-                    for (int i = 0; i < n; ++i) { if (DIAG) n_cand++; exact_test(i, std::true_type{}); }
-                }
-            }
-            RT_STAMP(5);
-            for (int seg0 = 0; seg0 < nt; seg0 += kSegTiles) {
-                const int seg_n = min(kSegTiles, nt - seg0);
-                const int nwords = seg_n >> 1;
-                for (int w = 0; w < nwords; ++w) bits_w[w * 64 + lane] = 0u;
-                s_sum[tid] = 0u;
-                __builtin_amdgcn_wave_barrier();
-                // Half a tile at a time: 4 MFMAs (2 ray groups x {HB, Q}), then the VALU looks at the
-                // 8 results per lane.  No software pipelining inside the wave: with 4 waves per SIMD
-                // the other waves fill the matrix pipe while this one looks (and registers are what
-                // buys the 4th wave).  B operand and K' of the next tile are fetched a tile ahead.
-                f32x4 hbA[2], qA[2];
-                bop_t b_cur = btab[seg0 * 64 + lane];
-                float k_cur = ktab[seg0 * 16 + col];
-                for (int tr = 0; tr < seg_n; ++tr) {
-                    RT_COUNT(7);
-                    const bop_t b_next = btab[(seg0 + tr + 1) * 64 + lane];
-                    const float k_next = ktab[(seg0 + tr + 1) * 16 + col];
-                    mfma_half(0, b_cur, hbA, qA);
-                    look_half(0, hbA, qA, k_cur, tr);
-                    mfma_half(1, b_cur, hbA, qA);
-                    look_half(1, hbA, qA, k_cur, tr);
-                    b_cur = b_next; k_cur = k_next;
-                }
-                __builtin_amdgcn_wave_barrier();
-                RT_STAMP(6);
-                enumerate(seg0);
-            }
-            finish_pool();
-            }
-#endif // RTIOW_CROSSCHECK_MODES
+#include "xcheck/rt_xcheck_scan.inc"       // else if constexpr (LIFTED) { mode 4 } else { modes 2, 3 }
+#endif
         }
         RT_STAMP(2);
         if (alive && !MATRIX) {
@@ -1313,6 +1016,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             tot_cand += pk & 0xFFFFFFFFull; tot_roots += pk >> 32;
         }
         RT_STAMP(3);
+        // ==== PHASE 4: shade ===================================================================================================
         // ---- (e) shade: main.rs:44-56 + materials.rs ----------------------------
         bool finished = false;                                          // this lane's sample ended in this pass
         D3 radiance = mk(0.0, 0.0, 0.0);
@@ -1360,9 +1064,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     double sx = u11_53(w.x, w.y), sy = u11_53(w.z, w.w), sz = u11_53(b1.x, b1.y);
                     bool ok = sx * sx + sy * sy + sz * sz < 1.0;
                     while (!ok) {
-#if !defined(RT_COUNT_ROWS) && !defined(RT_COUNT_ENUM)
-                        RT_COUNT(6);
-#endif
+                        RT_COUNT_MAIN(6);
                         U4 b = philox4x32_10(pix_global, (uint32_t)s, ev + nblk, 0u, P.k0, P.k1);
                         nblk++;
                         sx = u11_53(c0, c1); sy = u11_53(b.x, b.y); sz = u11_53(b.z, b.w);       // try 2m+1: ends its block
@@ -1392,9 +1094,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     if (!ok) {
                         uint32_t c0 = w.w;                                       // the word left over from the block before
                         do {
-#if !defined(RT_COUNT_ROWS) && !defined(RT_COUNT_ENUM)
-                            RT_COUNT(6);
-#endif
+                            RT_COUNT_MAIN(6);
                             U4 b = philox4x32_10(pix_global, (uint32_t)s, ev + nblk, 0u, P.k0, P.k1);
                             nblk++;
                             tx = c0; ty = b.x; tz = b.y;                         // try 4m+1
@@ -1485,6 +1185,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
         }
         RT_STAMP(13);
         __builtin_amdgcn_s_setprio(1);
+        // ==== PHASE 5: accumulate_finished =====================================================================================
         // ---- (f) finished samples -> their block's sums (LDS) or, without a ring entry, the frame buffer ----
         {
             // age of this lane's block among the wave's blocks (0 = the current one); blocks of age >= kRingDepth have
@@ -1492,12 +1193,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
             const uint32_t age = (blk_seq - (my_blk >> 4)) & 0x0FFFFFFFu;
             const bool direct = finished && !(P.use_ring && age < (uint32_t)kRingDepth);
             const bool ringed = finished && !direct;
-#ifdef RT_LDS_CONFLICTS
-            if (__ballot(ringed) != 0ull) {
-                unsigned long long *acc_d = ring_w + ((my_blk >> 4) & (uint32_t)(kRingDepth - 1)) * (kRingSlots * 3) + (my_blk & 15u) * 3u;
-                RT_LDS(1, 8, true, false, acc_d + 0, ringed); RT_LDS(1, 8, true, false, acc_d + 1, ringed); RT_LDS(1, 8, true, false, acc_d + 2, ringed);
-            }
-#endif
+            RT_LDS_RING_ADDS(ringed, my_blk);
             if (finished) {
                 const unsigned long long q0 = quantize(radiance.x), q1 = quantize(radiance.y), q2 = quantize(radiance.z);
                 if (ringed) {
@@ -1549,23 +1245,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
 
         // (end of the bounce loop body is stamped at the top of the next iteration as phase 4)
     // wave totals -> device counters
-#if defined(RT_EXIT_TIMES)
-    // Diagnostic build only: when (100 MHz real-time clock) the first/last/average wave leaves the kernel
-    if (lane == 0) {
-        const unsigned long long te = __builtin_amdgcn_s_memrealtime();
-        atomicMax(P.stats + 8, te); atomicMax(P.stats + 9, ~te); atomicAdd(P.stats + 10, te);
-        atomicMax(P.stats + 11, ~t_wave_start); atomicAdd(P.stats + 12, 1ull);
-    }
-#elif defined(RT_PHASE_STAMPS)
-    if (lane == 0) {
-        for (int k = 0; k < 8; ++k) atomicAdd(P.stats + 8 + k, ph[k]);
-        for (int k = 8; k < 16; ++k) atomicAdd(P.stats + 80 + (k - 8), ph[k]);      // finer split: see tools/phase_shares.py
-    }
-#elif defined(RT_BLOCK_COUNTS)
-    if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(P.stats + 8 + k, (unsigned long long)s_cnt[tid >> 6][k]);
-#elif defined(RT_LDS_CONFLICTS)
-    if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(P.stats + 8 + k, lds_x[k]);
-#endif
+    RT_DIAG_FLUSH();
     {
         const unsigned long long nc = tot_cand, nr = tot_roots;
         if (DIAG) {
@@ -1636,63 +1316,6 @@ __global__ void philox_kat_kernel(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
     out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
 }
 
-#ifdef RTIOW_CROSSCHECK_MODES
-// Known-answer hook for the matrix forms of the filter: one wave, 64 ray rows x 16 sphere
-// columns; returns HB and Q exactly as the render kernel's tiles compute them
-// (bf16x3 != 0: v_mfma_f32_16x16x32_bf16 on three-piece operands; else v_mfma_f32_16x16x4_f32).
-__global__ __launch_bounds__(64) void filter_products_kernel(const float *r1, const float *r2, const float *s,
-                                                           int bf16x3, float *hb_out, float *q_out)
-{
-    const int lane = threadIdx.x, col = lane & 15, quad = lane >> 4;
-    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    const float sv = s[col * 4 + quad];                     // S[k = quad][sphere = col]
-    for (int G = 0; G < 4; ++G) {
-        const float a1 = r1[(16 * G + col) * 4 + quad];     // R[ray 16G + (l&15)][k = l>>4]
-        const float a2 = r2[(16 * G + col) * 4 + quad];
-        f32x4 hb, q;
-        if (bf16x3) {
-            const Bf3 y = split_bf16x3(sv);
-            const uint4 bw = make_uint4(y.p1 | (y.p2 << 16), y.p1 | (y.p3 << 16), y.p2 | (y.p1 << 16), y.p3 | (y.p2 << 16));
-            const bf16x8 b = __builtin_bit_cast(bf16x8, bw);
-            hb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_operand_bf16x3(a1), b, zero, 0, 0, 0);
-            q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_operand_bf16x3(a2), b, zero, 0, 0, 0);
-        } else {
-            hb = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, sv, zero, 0, 0, 0);
-            q = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, sv, zero, 0, 0, 0);
-        }
-        for (int i = 0; i < 4; ++i) {                       // result (ray 16G + 4 quad + i, sphere col)
-            hb_out[(16 * G + 4 * quad + i) * 16 + col] = hb[i];
-            q_out[(16 * G + 4 * quad + i) * 16 + col] = q[i];
-        }
-    }
-}
-
-// One tile of the MODE 4 filter exactly as the render kernel evaluates it: 64 rays (o, d in f64,
-// [64][3]) against the 16 columns of `tile` ([2][64] B operands built by the host exactly as
-// rt_upload_scene builds them).  D_out[ray][column], R_out[ray][0..10] = the per-ray terms.
-__global__ __launch_bounds__(64) void lifted_products_kernel(const double *o, const double *d, const uint4 *tile,
-                                                           float *D_out, float *R_out)
-{
-    __shared__ uint4 stage[32 * kStageStride];
-    const int lane = threadIdx.x, col = lane & 15, quad = lane >> 4;
-    const LiftedRay L = make_lifted(mk(o[3 * lane], o[3 * lane + 1], o[3 * lane + 2]),
-                                    mk(d[3 * lane], d[3 * lane + 1], d[3 * lane + 2]));
-    for (int k = 0; k < kLiftTerms - 1; ++k) R_out[lane * kLiftTerms + k] = L.r[k];
-    R_out[lane * kLiftTerms + kLiftTerms - 1] = L.sane ? 1.0f : 0.0f;
-    bf16x8 A[4][2];
-    uint32_t w[32];
-    lifted_a_words(L, w);
-    lifted_stage_operands(stage, lane, w, A);
-    const bf16x8 b0 = __builtin_bit_cast(bf16x8, tile[lane]), b1 = __builtin_bit_cast(bf16x8, tile[64 + lane]);
-    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int G = 0; G < 4; ++G) {
-        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[G][0], b0, zero, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[G][1], b1, acc, 0, 0, 0);
-        for (int i = 0; i < 4; ++i) D_out[(16 * G + 4 * quad + i) * 16 + col] = acc[i];
-    }
-}
-
-#endif // RTIOW_CROSSCHECK_MODES
 
 // One tile of the MODE 5 (tube) filter exactly as the render kernel evaluates it: 64 rays against
 // the 32 columns of `tile`.  h_out[ray][column][k] = lambda u_k.(c - o) as the matrix pipe returns it;
@@ -1750,3 +1373,7 @@ __global__ void unit_accept_kernel(const uint32_t *w, int n, uint32_t *acc, doub
 }
 
 } // namespace rt
+
+#ifdef RTIOW_CROSSCHECK_MODES
+#include "xcheck/rt_xcheck_kernels.hpp"    // known-answer kernels of modes 2-4
+#endif
