@@ -56,11 +56,12 @@ SPEC_CLOCK_GHZ = 2.4                   # MI355X_MICROARCH.md: peak engine clock
 # 8 for the transcendental unit (v_rcp/v_rsq/v_sqrt_f32)
 ISSUE_CYCLES = {"plain": 2.0, "f64": 4.0, "trans": 8.0}
 
-KERNEL_SOURCES = ("rtiow_amd/csrc/rt_kernels.hpp", "rtiow_amd/csrc/rt_device.hpp", "rtiow_amd/csrc/rt_api.hip")
+KERNEL_SOURCES = ("rtiow_amd/csrc/rt_kernels.hpp", "rtiow_amd/csrc/rt_device.hpp", "rtiow_amd/csrc/rt_api.hip", "rtiow_amd/csrc/rt_diag.hpp")
 
 
 def kernel_source_sha():
-    """Identifies the kernel a profile was taken on: sha256 over the three kernel sources."""
+    """Identifies the kernel a profile was taken on: sha256 over the product's kernel sources (csrc/xcheck/ belongs to the cross-check
+    build only)."""
     h = hashlib.sha256()
     for rel in KERNEL_SOURCES:
         with open(os.path.join(ROOT, rel), "rb") as f:

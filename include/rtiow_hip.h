@@ -240,7 +240,7 @@ int rt_render_rgba8(rt_context *ctx, const rt_camera *cam, const rt_params *p, i
 const char *rt_last_error(void);
 const char *rt_backend_name(void);     /* "hip-gfx950" */
 int32_t rt_abi_version(void);
-/* sha256 (first 16 hex digits) over the three kernel sources this library was BUILT from, as the build recorded it
+/* sha256 (first 16 hex digits) over the product kernel sources (csrc/rt_*.hpp, rt_api.hip) this library was BUILT from, as the build recorded it
  * ("unknown" for a build that did not pass it): bench.py labels its line with it, so that a stale .so shows */
 const char *rt_build_source_sha(void);
 /* Known-answer test hooks, computed ON THE DEVICE:

@@ -447,12 +447,13 @@ __device__ __forceinline__ void tube_a_words(const TubeRay &T, uint32_t (&w)[2][
             w[k][2 * i + 1] = pk(r1, r1);                                       // p2 | p2 << 16
         }
         // t in three pieces (the third is exact: at most 8 significant bits are left), then the 1 of K-slot 15
+        // (pk(0, t) IS the f32 value of t's first piece, p1 << 16, and pk(t, r1) the dword p1 | p2 << 16 in one conversion -- the low half converts
+        //  t again: six instructions where converting (t, t) and (r1, r1) and masking and merging the halves took eight)
         const float t = T.t[k];
-        const uint32_t c1 = pk(t, t);
-        const float r1 = t - __uint_as_float(c1 & 0xFFFF0000u);
-        const uint32_t c2 = pk(r1, r1);
-        const float r2 = r1 - __uint_as_float(c2 & 0xFFFF0000u);
-        w[k][6] = (c1 & 0xFFFFu) | (c2 & 0xFFFF0000u);                          // p1 | p2 << 16
+        const float r1 = t - __uint_as_float(pk(0.0f, t));
+        const uint32_t c12 = pk(t, r1);                                         // p1 | p2 << 16
+        const float r2 = r1 - __uint_as_float(c12 & 0xFFFF0000u);
+        w[k][6] = c12;
         w[k][7] = pk(r2, 1.0f);                     // p3 | 1 << 16; slot 15: 1 (against 0, or 4 in a never-kept column)
     }
 }

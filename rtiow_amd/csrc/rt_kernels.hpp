@@ -608,7 +608,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 unsigned summary = 0u, word = 0u;
                 if constexpr (TUBE) {
                     // which of the segment's words hold a candidate of this ray (the recording side sets bits only)
-                    for (int w = 0; w < nwords_tube; ++w) summary |= bits_w[w * 64 + lane] != 0u ? 1u << w : 0u;
+                    // (min(word, 1) << w | summary: a v_min_u32 and a v_lshl_or_b32 per word where `word != 0 ? 1 << w : 0` is a compare, a select and an or)
+                    for (int w = 0; w < nwords_tube; ++w) summary |= min(bits_w[w * 64 + lane], 1u) << w;
                     if (!alive) summary = 0u;
                 } else {
                     summary = alive ? s_sum[tid] : 0u;

@@ -182,12 +182,14 @@ def phases_table(lines, counts):
         ("enumerate: per trip of the bitmap walk", enum_loop, enum_end, c["enum_trips"], 1),
         ("enumerate: summary words", enum0, enum_loop - 1, 1.0, 1),
         ("finish pool / take the minimum", fin0, fin_end, 1.0, 1),
-        ("ground sphere exact test (always-exact list)", exact0, exact_end, 1.0, 1),
+        ("ground sphere exact test (always-exact list)", exact0, exact_end, 1.0, 3),      # three inlined copies (first always-exact sphere, the loop over
+                                                                                      # further ones, the in-order form for out-of-range rays): the first runs
         ("tile loop: per tile (B operand, list entry, dispatch)", dotile0, loop_end, c["tiles"], 3),
         ("tile loop: per segment (zero the words, list read)", loop0, dotile0 - 1, 1.0, 1),
         ("footprints + tile list", which0, loop0 - 1, 1.0, 1),
         ("filter rows: make_tube, bf16 pieces, staging", tube0, always0 - 1, 1.0, 1),
-        ("always-exact list, out-of-range rays", always0, seed0 - 1, 1.0, 1),
+        ("always-exact list, out-of-range rays", always0, seed0 - 1, c["always_extra"], 1),   # loop control + the whole-list scan of a ray outside the
+                                                                                          # filter's range: (all but) never on these scenes
         ("refill: start 64 samples (item -> pixel, Philox, lens)", refill0, refill_end, c["refills"], 1),
         ("take samples from the queue", take0, cam0 - 1, 1.0 + c["refills"], 1),
         ("camera ray of fresh lanes (camera.rs:47-54)", cam0, hit0 - 1, 1.0, 1),
@@ -216,10 +218,10 @@ def main():
     extra = [a for a in args if a.startswith("-D")]
     # measured trips per wave-bounce (profiles/r04_block_counts.txt: 1200x675x100; r04_block_counts_cfg4.txt: 10k spheres)
     counts = ({"looks": 20.0, "keeps": 14.03, "halves": 21.56, "pool_rounds": 1.90, "enum_trips": 5.6, "tiles": 8.43, "refills": 0.355,
-               "retry_blocks": 3.8, "flushes": 0.36 / 16.0}
+               "retry_blocks": 3.8, "flushes": 0.36 / 16.0, "always_extra": 0.3}
               if tenk else
               {"looks": 15.22, "keeps": 10.18, "halves": 16.24, "pool_rounds": 1.62, "enum_trips": 4.6, "tiles": 5.35, "refills": 0.377,
-               "retry_blocks": 3.72, "flushes": 0.377 / 4.0})
+               "retry_blocks": 3.72, "flushes": 0.377 / 4.0, "always_extra": 0.1})
     elf, dis = build(extra)
     ins = kernel_instructions(dis, want)
     if not ins:

@@ -11,7 +11,7 @@ run_cfg() {
   OUT=gpurun_out/prof_$TAG
   rm -rf $OUT; mkdir -p $OUT
   STEPS=5; [ "$TAG" = weak ] && STEPS=2
-  ARGS="bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-other-configs $@"
+  ARGS="bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-other-configs --no-end-to-end $@"
   echo "$ARGS" > $OUT/command.txt
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
   echo "$TAG trace rc=$?"

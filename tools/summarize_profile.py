@@ -22,11 +22,12 @@ for cfg, shape in CONFIGS.items():
     shutil.copy(ks, os.path.join(root, "profiles", f"{tag}_kernel_stats_{cfg}.csv"))
     rows = list(csv.DictReader(open(ks)))
     out["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage") if k in r} for r in rows[:5]]
+    top_kernel = rows[0]["Name"].split("(")[0]            # only the launches of the timed configuration's kernel enter the means
     pm = {}
     for f in [newest(os.path.join(d, "*", "*_counter_collection.csv")) for d in sorted(glob.glob(os.path.join(prof, "pmc[0-9]*"))) if os.path.isdir(d)]:
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "render_kernel" in r["Kernel_Name"]:
+            if r["Kernel_Name"].split("(")[0] == top_kernel:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 out["vgpr_count"], out["lds_block_size"] = r["VGPR_Count"], r["LDS_Block_Size"]
         for k, v in agg.items():
