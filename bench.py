@@ -482,6 +482,12 @@ def main():
                                        f"instruction of this mix ({n_f64 / n_valu:.3f} f64 add/mul/fma at 4, "
                                        f"{n_trans / n_valu:.4f} transcendental at 8, the rest at 2)")
                 roof["valu_busy"] = pmc.get("valu_busy")
+                # `frac` prices whatever the kernel issues: an optimisation that REMOVES instructions lowers it (round 5: 0.53 -> 0.51 while the
+                # frame got 2 % faster).  The figure that cannot be gamed that way: the share of the kernel's time that the f64 add/mul/fma the
+                # reference's arithmetic REQUIRES (its divisions' and square roots' expansions included) would take alone at the hardware's f64
+                # issue rate (4 cycles per wave-instruction) -- everything else the kernel issues is this implementation's overhead.
+                if n_f64:
+                    roof["frac_required_f64_only"] = round(n_f64 * ISSUE_CYCLES["f64"] / (N_SIMD * SPEC_CLOCK_GHZ * 1e9) / (k_ms * 1e-3), 4)
                 roof["issue"] = {
                     "valu_insts_per_launch": n_valu,
                     "valu_insts_per_wave_bounce": round(n_valu / wave_bounces, 1),

@@ -64,7 +64,7 @@ def test_recorded_bench_line_has_the_contracts_fields():
     """The line recorded in profiles/ (this round's last `python bench.py --steps 20 --warmup 5` on an MI355X) carries every
     field the driver and the judge read, and its roofline numbers are consistent with each other."""
     import json
-    path = os.path.join(ROOT, "profiles", "r04_bench_n1.json")
+    path = os.path.join(ROOT, "profiles", "r05_bench_n1.json")
     d = json.loads(open(path).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "rmse_vs_cpu", "parity_vs_cpu"):
@@ -88,6 +88,13 @@ def test_recorded_bench_line_has_the_contracts_fields():
     assert d["config"]["library_source_sha"] == cfg["kernel_source_sha"]
     assert abs(r["kernel_ms"] - r["kernel_ms_rocprof_avg"]) < 0.03 * r["kernel_ms"]         # HIP events vs rocprofv3 --stats
     assert r["kernel_ms"] <= d["ms_per_step"]
+    # SURVEY 8(d)'s separate end-to-end figure: the host-buffer calls of main.rs:122-145, never `value`; the one-call form costs < 0.6 ms over its kernel
+    e = d["end_to_end"]
+    for cfg in ("headline", "configs[1]"):
+        assert e[cfg]["same_bytes"] is True and 0.0 < e[cfg]["one_call"]["overhead_ms"] <= 0.6 < 3.0
+        assert e[cfg]["one_call"]["ms"] <= e[cfg]["two_calls"]["ms"] and e[cfg]["one_call"]["ms"] >= e[cfg]["one_call"]["kernel_ms"]
+    assert (e["headline"]["width"], e["headline"]["height"], e["headline"]["spp"]) == (1200, 675, 500) and e["configs[1]"]["spp"] == 100
+    assert any("UNIFORM53" in o.get("config", "") for o in d["other_configs"])          # the price of 53-bit draws, in the driver's own line
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -96,7 +103,7 @@ def test_recorded_bench_line_has_the_contracts_fields():
     #  nulls the replayed counters when the sources have moved on)
     if cfg["kernel_source_sha"] != bench.kernel_source_sha():
         import pytest
-        pytest.skip("profiles/r04_bench_n1.json was recorded on other kernel sources (%s)" % cfg["kernel_source_sha"])
+        pytest.skip("profiles/r05_bench_n1.json was recorded on other kernel sources (%s)" % cfg["kernel_source_sha"])
 
 
 def test_rmse_helper_on_the_two_oracles():
