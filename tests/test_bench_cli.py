@@ -90,9 +90,9 @@ def test_recorded_bench_line_has_the_contracts_fields():
     assert r["kernel_ms"] <= d["ms_per_step"]
     # SURVEY 8(d)'s separate end-to-end figure: the host-buffer calls of main.rs:122-145, never `value`; the one-call form costs < 0.6 ms over its kernel
     e = d["end_to_end"]
-    for cfg in ("headline", "configs[1]"):
-        assert e[cfg]["same_bytes"] is True and 0.0 < e[cfg]["one_call"]["overhead_ms"] <= 0.6 < 3.0
-        assert e[cfg]["one_call"]["ms"] <= e[cfg]["two_calls"]["ms"] and e[cfg]["one_call"]["ms"] >= e[cfg]["one_call"]["kernel_ms"]
+    for which in ("headline", "configs[1]"):
+        assert e[which]["same_bytes"] is True and 0.0 < e[which]["one_call"]["overhead_ms"] <= 0.6
+        assert e[which]["one_call"]["ms"] <= e[which]["two_calls"]["ms"] and e[which]["one_call"]["ms"] >= e[which]["one_call"]["kernel_ms"]
     assert (e["headline"]["width"], e["headline"]["height"], e["headline"]["spp"]) == (1200, 675, 500) and e["configs[1]"]["spp"] == 100
     assert any("UNIFORM53" in o.get("config", "") for o in d["other_configs"])          # the price of 53-bit draws, in the driver's own line
     c = d["cpu_baseline"]
