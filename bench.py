@@ -548,6 +548,7 @@ def main():
             # the other single-GPU BASELINE configurations, a few launches each (kernel time, HIP events)
             others = []
             try:
+                others.append({"config": "configs[0] book-1 400x225x10 (the reference's own CPU-runnable case)", **time_config(rt, torch, renderer, flat, 400, 225, 10, 10, stream)})
                 others.append({"config": "configs[1] book-1 1200x675x100", **time_config(rt, torch, renderer, flat, 1200, 675, 100, 10, stream)})
                 # the price of the reference's exact bit count: every draw from TWO Philox words (53 random bits, rand 0.8.5's gen::<f64>())
                 # instead of one word's 32 -- another valid stream, the same frame statistically
