@@ -4,12 +4,15 @@
 //
 //   rtiow_render [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--scene-seed S]
 //                [--grid LO HI] [--device K] [--out image.png|image.ppm] [--dump-scene scene.bin] [--scene scene.bin]
-//                [--devices 0,1,..  [--tile-rows T] [--force-rccl]] [--uniform53] [--two-calls]
+//                [--devices 0,1,..  [--tile-rows T] [--force-rccl]] [--uniform53] [--two-calls] [--passes N]
 //   rtiow_render --reassembly-plan H T N     (no GPU: the strided copies that put N shards' rows back in image order)
 //   rtiow_render --test-png W H out.png      (no GPU: a fixed pattern through the PNG writer -- r = 7x + 13y, g = x ^ y, b = x y, mod 256, alpha 255)
 //
 // Single device: ONE call, rt_render_rgba8 (the sums stay on the device); --two-calls takes them through host memory
 // instead (rt_render, then rt_resolve_rgba8): the same bytes.
+// --passes N: main.rs:130-137's sample loop as N additive launches (sample_begin, RT_FLAG_ACCUMULATE) issued alternately on TWO streams of one
+// context, so that pass k + 1 fills the end-of-launch tail of pass k (a context holds two launches' state); the sums are exact integers, so the
+// image is the one the single call gives, byte for byte.
 // --devices: the frame's rows are dealt round-robin to one rt_context per listed device, each driven by
 // its own host thread, and gathered with ONE RCCL ncclGather to the first device (host/rtiow_multi.hpp).
 // A device may be listed more than once (two contexts on one GPU from two threads: the threading rule of
@@ -36,6 +39,7 @@ int main(int argc, char **argv)
     std::string out = "image.ppm", dump, scene_file;
     std::vector<int> devices;                    // --devices 0,1,...: one context + host thread per entry
     bool force_rccl = false, uniform53 = false, two_calls = false;
+    int passes = 1;
     int tile_rows = 1;
     if (argc == 5 && !std::strcmp(argv[1], "--reassembly-plan")) {
         const int H = std::atoi(argv[2]), T = std::atoi(argv[3]), n = std::atoi(argv[4]);
@@ -72,6 +76,7 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--force-rccl")) force_rccl = true;
         else if (!std::strcmp(argv[i], "--uniform53")) uniform53 = true;
         else if (!std::strcmp(argv[i], "--two-calls")) two_calls = true;
+        else if (arg("--passes")) passes = std::atoi(argv[++i]);
         else if (arg("--dump-scene")) dump = argv[++i];
         else if (arg("--scene")) scene_file = argv[++i];
         else if (!std::strcmp(argv[i], "--grid") && i + 2 < argc) { lo = std::atoi(argv[++i]); hi = std::atoi(argv[++i]); }
@@ -124,7 +129,41 @@ int main(int argc, char **argv)
         if (rc) return die("rt_create", rc);
         rc = rt_upload_scene(ctx, flat.data(), (int32_t)flat.size());
         if (rc) return die("rt_upload_scene", rc);
-        if (two_calls) {                         // the sums through host memory: rt_render, then rt_resolve_rgba8 (same bytes)
+        if (passes > 1) {
+            // progressive passes, overlapped: device buffers, two streams, every pass adds its samples to the same exact sums
+            if (passes > spp) { std::fprintf(stderr, "--passes %d: more passes than samples per pixel\n", passes); return 2; }
+            auto hip_die = [](hipError_t e, const char *what) { std::fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return 1; };
+            hipError_t e = hipSetDevice(device);
+            if (e != hipSuccess) return hip_die(e, "hipSetDevice");
+            hipStream_t st2[2] = {nullptr, nullptr};
+            void *d_fix = nullptr, *d_rgba = nullptr;
+            for (int k = 0; k < 2; ++k) if ((e = hipStreamCreateWithFlags(&st2[k], hipStreamNonBlocking)) != hipSuccess) return hip_die(e, "hipStreamCreate");
+            if ((e = hipMalloc(&d_fix, npix * 3 * sizeof(uint64_t))) != hipSuccess) return hip_die(e, "hipMalloc");
+            if ((e = hipMalloc(&d_rgba, npix * 4)) != hipSuccess) return hip_die(e, "hipMalloc");
+            if ((e = hipMemset(d_fix, 0, npix * 3 * sizeof(uint64_t))) != hipSuccess) return hip_die(e, "hipMemset");      // zero BEFORE any stream adds to it
+            unsigned long long rays = 0;
+            float kernel_ms = 0.0f;
+            int begin = 0;
+            for (int k = 0; k < passes; ++k) {
+                rt_params q = p;
+                q.spp = spp / passes + (k < spp % passes ? 1 : 0);      // the samples dealt as evenly as they go
+                q.sample_begin = begin; q.flags |= RT_FLAG_ACCUMULATE;
+                begin += q.spp;
+                rc = rt_render_device(ctx, &rc_cam, &q, d_fix, st2[k & 1]);
+                if (rc) return die("rt_render_device", rc);
+            }
+            for (int k = 0; k < 2; ++k) if ((e = hipStreamSynchronize(st2[k])) != hipSuccess) return hip_die(e, "hipStreamSynchronize");
+            rc = rt_last_stats(ctx, &st);                                // (the latest launch only; the ray count below is the frame's)
+            if (rc) return die("rt_last_stats", rc);
+            rays = st.rays_traced * (unsigned long long)passes; kernel_ms = st.kernel_ms * passes;   // (an estimate for the summary line)
+            st.rays_traced = rays; st.kernel_ms = kernel_ms;
+            rc = rt_resolve_rgba8_device(ctx, d_fix, width, height, spp, 1, d_rgba, st2[0]);
+            if (rc) return die("rt_resolve_rgba8_device", rc);
+            if ((e = hipMemcpyAsync(rgba.data(), d_rgba, npix * 4, hipMemcpyDeviceToHost, st2[0])) != hipSuccess) return hip_die(e, "hipMemcpyAsync");
+            if ((e = hipStreamSynchronize(st2[0])) != hipSuccess) return hip_die(e, "hipStreamSynchronize");
+            (void)hipFree(d_fix); (void)hipFree(d_rgba);
+            for (int k = 0; k < 2; ++k) (void)hipStreamDestroy(st2[k]);
+        } else if (two_calls) {                  // the sums through host memory: rt_render, then rt_resolve_rgba8 (same bytes)
             std::vector<uint64_t> fix(npix * 3);
             rc = rt_render(ctx, &rc_cam, &p, nullptr, fix.data(), &st);                  // main.rs:122-136
             if (rc) return die("rt_render", rc);

@@ -49,3 +49,21 @@ def test_two_launches_in_flight_keep_their_own_counters(renderer, oracle_mod, bo
     assert np.array_equal(fa.cpu().numpy().view(np.uint64), wa)
     assert np.array_equal(fb.cpu().numpy().view(np.uint64), wb)
     assert st_b["samples"] == 120 * 67 * 5 and st_b["rays_traced"] == stb["rays_traced"]
+
+
+def test_cpp_cli_overlapping_passes_write_the_single_calls_image(tmp_path):
+    """host/rtiow_render --passes N: the compiled host issues N additive launches alternately on two streams of one context
+    (rt_render_device + RT_FLAG_ACCUMULATE, then rt_resolve_rgba8_device); the image file is the single call's, byte for byte."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "host", "rtiow_render")
+    if not os.path.exists(exe):
+        pytest.skip("host CLI not built")
+    one, many, odd = (str(tmp_path / n) for n in ("one.ppm", "many.ppm", "odd.ppm"))
+    base = [exe, "--width", "160", "--height", "90", "--spp", "123", "--seed", "4"]
+    subprocess.run(base + ["--out", one], check=True, timeout=300)
+    subprocess.run(base + ["--out", many, "--passes", "3"], check=True, timeout=300)       # 41 samples per pass: LDS block sums
+    subprocess.run(base + ["--out", odd, "--passes", "7"], check=True, timeout=300)        # 18 / 17 samples per pass: direct adds, uneven passes
+    ref = open(one, "rb").read()
+    assert open(many, "rb").read() == ref and open(odd, "rb").read() == ref
