@@ -574,6 +574,7 @@ def main():
                             "pageable host buffers): one_call = rt_render_rgba8, two_calls = rt_render + rt_resolve_rgba8",
                     "headline": end_to_end(rt, renderer, W, H, spp_frame, 5),
                     "configs[1]": end_to_end(rt, renderer, 1200, 675, 100, 10),
+                    "configs[2]": end_to_end(rt, renderer, 3840, 2160, 500, 2),      # (33 MB of RGBA8; the sums are 199 MB)
                 }
             except Exception as e:
                 out["end_to_end"] = {"error": str(e)}
