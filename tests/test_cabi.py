@@ -95,3 +95,20 @@ def test_no_cpu_fallback_without_a_gpu():
     with pytest.raises(rt.RtiowHipError) as e:
         rt.Renderer(0)
     assert "no HIP device" in str(e.value) or "fallback" in str(e.value)
+
+
+def test_product_library_carries_no_crosscheck_kernels():
+    """Scan modes 2-4 live in rtiow_amd/csrc/xcheck/ and are compiled only into tools/librtiow_hip_xcheck.so: the product library's
+    device code holds render_kernel<0|1|5, ...> instantiations only (the kernel names are in the .so's embedded code object)."""
+    import re
+    blob = open(_ffi.LIB_PATH if "RTIOW_HIP_LIB" not in os.environ else os.path.join(ROOT, "rtiow_amd", "librtiow_hip.so"), "rb").read()
+    modes = set(int(m) for m in re.findall(rb"_ZN2rt13render_kernelILi(\d)E", blob))
+    assert modes == {0, 1, 5}, modes
+    x = os.path.join(ROOT, "tools", "librtiow_hip_xcheck.so")
+    if os.path.exists(x):
+        xmodes = set(int(m) for m in re.findall(rb"_ZN2rt13render_kernelILi(\d)E", open(x, "rb").read()))
+        assert xmodes == {0, 1, 2, 3, 4, 5}, xmodes
+    # ... and the product sources hold none of their definitions (only the include stubs under RTIOW_CROSSCHECK_MODES)
+    for rel in ("rt_kernels.hpp", "rt_device.hpp", "rt_api.hip"):
+        src = open(os.path.join(ROOT, "rtiow_amd", "csrc", rel)).read()
+        assert "LiftedRay make_lifted" not in src and "a_operand_bf16x3(float" not in src and "auto check_sign_half" not in src, rel
