@@ -5,7 +5,8 @@
 //                        stats[80..87]; the stamps serialise the phases: read the SHARES (tools/phase_shares.py)
 //   -DRT_BLOCK_COUNTS    wave-level execution counts of the main blocks into stats[8..15] (tools/block_counts.py); with
 //                        -DRT_COUNT_ROWS counters 1 and 6 count the large grid's footprint-row and list-emission trips, with
-//                        -DRT_COUNT_ENUM the enumeration's trips and the candidates it pushes, instead of refills and redraw trips
+//                        -DRT_COUNT_ENUM the enumeration's trips and the candidates it pushes, with -DRT_COUNT_REDRAW the lanes that draw a unit-sphere
+//                        sample and those that fail try 0, instead of refills and redraw trips
 //   -DRT_EXIT_TIMES      when the first / last / average wave leaves the kernel (100 MHz real-time clock; tools/exit_times.py)
 //   -DRT_LDS_CONFLICTS   a software model of the LDS bank serialisation at every LDS site of the kernel (tools/lds_conflicts.py)
 //
@@ -31,6 +32,7 @@
 #define RT_COUNT_MAIN(k) RT_DIAG_NOTHING                /* counters 1 / 6 in their default meaning (refills, redraw trips) */
 #define RT_COUNT_ROWS_TRIP(k) RT_DIAG_NOTHING           /* ... as the large grid's footprint-row / list-emission trips (-DRT_COUNT_ROWS) */
 #define RT_COUNT_ENUM_TRIP(m) RT_DIAG_NOTHING           /* ... as the enumeration's trips and pushed candidates (-DRT_COUNT_ENUM) */
+#define RT_COUNT_REDRAW_LANES(ok) RT_DIAG_NOTHING       /* ... as the lanes that draw a unit-sphere sample and those that fail try 0 (-DRT_COUNT_REDRAW) */
 #define RT_LDS(site, BYTES, ATOMIC, LOAD64, ptr, active) RT_DIAG_NOTHING
 #define RT_LDS_N(site, n, BYTES, ATOMIC, LOAD64, byte_addr, active) RT_DIAG_NOTHING
 #define RT_LDS_QUEUE_READS(take, entry) RT_DIAG_NOTHING
@@ -78,6 +80,10 @@
 #elif defined(RT_COUNT_ENUM)
 #undef RT_COUNT_ENUM_TRIP
 #define RT_COUNT_ENUM_TRIP(m) do { RT_COUNT(1); RT_COUNT_N(6, __popcll(m)); } while (0)
+#elif defined(RT_COUNT_REDRAW)
+#undef RT_COUNT_REDRAW_LANES
+#define RT_COUNT_REDRAW_LANES(ok) do { const unsigned n1_ = (unsigned)__popcll(__ballot(true)), n6_ = (unsigned)__popcll(__ballot(!(ok))); \
+                                       RT_COUNT_N(1, n1_); RT_COUNT_N(6, n6_); } while (0)      /* (the ballots BEFORE RT_COUNT_N narrows to its leader lane) */
 #else
 #undef RT_COUNT_MAIN
 #define RT_COUNT_MAIN(k) RT_COUNT(k)

@@ -1092,6 +1092,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                     // four tries per three blocks.
                     uint32_t tx = w.x, ty = w.y, tz = w.z, nblk = 1u;
                     bool ok = unit_sphere_accepts(tx, ty, tz);
+                    RT_COUNT_REDRAW_LANES(ok);                                   // (diagnostic builds: lanes that draw a unit-sphere sample / that fail try 0)
                     if (!ok) {
                         uint32_t c0 = w.w;                                       // the word left over from the block before
                         do {
