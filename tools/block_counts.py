@@ -12,6 +12,7 @@ r = rt.Renderer(0)
 big = os.environ.get("SCENE") == "cfg4"
 r.upload_scene(rt.random_scene(1, grid=(-50, 49) if big else (-11, 11)).flatten())
 w, h, spp = (1920, 1080, 32) if big else (1200, 675, 100)
+spp = int(os.environ.get("SPP", spp))
 sm, fix, st = r.render(rt.book1_camera(w, h), rt.make_params(w, h, spp), want_fix=False)
 out = (C.c_ulonglong * 8)()
 r._lib.rt_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]

@@ -14,6 +14,7 @@ for mode in [int(x) for x in os.environ.get("MODES", "4").split(",")]:
     big = os.environ.get("SCENE") == "cfg4"                      # the 10k-sphere scene instead of the book scene
     r.upload_scene(rt.random_scene(1, grid=(-50, 49) if big else (-11, 11)).flatten())
     w, h, spp = (1920, 1080, 32) if big else (1200, 675, 100)
+    spp = int(os.environ.get("SPP", spp))
     for _ in range(2):
         sm, fix, st = r.render(rt.book1_camera(w, h), rt.make_params(w, h, spp), want_fix=False)
     out = (C.c_ulonglong * 16)()
