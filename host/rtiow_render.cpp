@@ -10,7 +10,7 @@
 //
 // Single device: ONE call, rt_render_rgba8 (the sums stay on the device); --two-calls takes them through host memory
 // instead (rt_render, then rt_resolve_rgba8): the same bytes.
-// --passes N: main.rs:130-137's sample loop as N additive launches (sample_begin, RT_FLAG_ACCUMULATE) issued alternately on TWO streams of one
+// --passes N: main.rs:130-137's sample loop as N additive launches (sample_begin, RT_FLAG_ACCUMULATE | RT_FLAG_OVERLAPPED) issued alternately on TWO streams of one
 // context, so that pass k + 1 fills the end-of-launch tail of pass k (a context holds two launches' state); the sums are exact integers, so the
 // image is the one the single call gives, byte for byte.
 // --devices: the frame's rows are dealt round-robin to one rt_context per listed device, each driven by
@@ -147,7 +147,7 @@ int main(int argc, char **argv)
             for (int k = 0; k < passes; ++k) {
                 rt_params q = p;
                 q.spp = spp / passes + (k < spp % passes ? 1 : 0);      // the samples dealt as evenly as they go
-                q.sample_begin = begin; q.flags |= RT_FLAG_ACCUMULATE;
+                q.sample_begin = begin; q.flags |= RT_FLAG_ACCUMULATE | RT_FLAG_OVERLAPPED;
                 begin += q.spp;
                 rc = rt_render_device(ctx, &rc_cam, &q, d_fix, st2[k & 1]);
                 if (rc) return die("rt_render_device", rc);

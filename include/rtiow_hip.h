@@ -116,6 +116,10 @@ typedef struct {
                                     (the default: u = w * 2^-32, symmetric ranges (int32_t)w * 2^-31; ABI <= 4: 24 bits); same draw
                                     order; another (equally valid) random stream, so frames differ from the default's; scan mode 5 or
                                     RT_FLAG_NO_FILTER, not with RT_FLAG_DIAG_STATS */
+#define RT_FLAG_OVERLAPPED 0x10u /* rt_render_device: this launch is one of a sequence of passes that OVERLAP on two streams (below): the next
+                                    pass fills its end-of-launch tail, so it takes the work blocks of 1 024 pixel-samples whatever its size
+                                    (alone, a launch of < 2^28 pixel-samples is up to 6 % slower on them: its last blocks are its tail).
+                                    The same frame either way; 2 x 250 spp at 1200x675: 1.045 -> 1.012 x one 500-spp launch */
 
 typedef struct {
     uint64_t samples;            /* pixel-samples finished                          */
@@ -131,7 +135,7 @@ typedef struct {
     int32_t  kernel_variant;     /* which instantiation of the kernel ran, as bits: 1 the scan_mode-5 kernel for scenes whose
                                     tile grid has <= 64 cells (else the general one, and every other scan mode); 2 the
                                     RT_FLAG_UNIFORM53 instantiation; 4 work blocks of 1 024 pixel-samples instead of 256 (launches of
-                                    >= 2^28 pixel-samples at >= 147 samples per pixel) */
+                                    >= 2^28 pixel-samples at >= 147 samples per pixel; >= 69 on the small-grid kernel) */
     uint64_t live_per_bounce[64]; /* rays traced at bounce index k (0 = camera ray; indices >= 63 share the
                                     last slot); sums to rays_traced (RT_FLAG_DIAG_STATS, else 0) */
     uint64_t direct_samples;     /* samples added to the frame buffer one by one instead of through their block's
@@ -147,7 +151,7 @@ typedef struct {
  *   RTIOW_BLOCKS_PER_CU=k          rt_create: workgroups per CU of the persistent grid (default: the occupancy query)
  *   RTIOW_RING_MIN_SPP=n           rt_create: per-block pixel sums in LDS from n samples per pixel on (default and minimum 37)
  *   RTIOW_LARGE_BLOCK_MIN_ITEMS=n  per launch: work blocks of 1 024 pixel-samples instead of 256 from n pixel-samples per launch on
- *                                  (default 2^28; also needs >= 147 samples per pixel; rt_stats.kernel_variant bit 2 says which ran) */
+ *                                  (default 2^28; also needs >= 147 samples per pixel, 69 on the small-grid kernel; rt_stats.kernel_variant bit 2 says which ran) */
 
 /* ---- lifetime -------------------------------------------------------------- */
 
@@ -197,7 +201,7 @@ int rt_render(rt_context *ctx, const rt_camera *cam, const rt_params *p,
 /* Device-buffer form, asynchronous on `stream` (a hipStream_t, or NULL for the
  * default stream).  d_fix: device pointer to [rows][width][3] u64.
  * Progressive passes (main.rs:130-137 split over launches with sample_begin and RT_FLAG_ACCUMULATE): the sums are exact
- * integers added with atomics, so passes may OVERLAP -- issue pass k + 1 on another stream than pass k and it fills the tail
+ * integers added with atomics, so passes may OVERLAP -- issue pass k + 1 on another stream than pass k (and say so: RT_FLAG_OVERLAPPED) and it fills the tail
  * of pass k (the last paths of a launch leave most of the chip idle: 5 % of a 100-spp launch at 1200x675).  A context holds
  * the per-launch state of two launches; a third launch makes ITS stream wait for the one before the previous (no host wait).
  * The caller orders what must be ordered: the buffer is zeroed (by a launch without RT_FLAG_ACCUMULATE, or by the caller)

@@ -42,6 +42,7 @@ RT_FLAG_ACCUMULATE = 0x1
 RT_FLAG_NO_FILTER = 0x2
 RT_FLAG_DIAG_STATS = 0x4
 RT_FLAG_UNIFORM53 = 0x8
+RT_FLAG_OVERLAPPED = 0x10
 
 # every symbol include/rtiow_hip.h declares: (name, restype, argtypes)
 _VP = C.c_void_p

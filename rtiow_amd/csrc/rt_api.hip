@@ -656,13 +656,15 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     // blocks of kItemBlock consecutive items; the work counter counts blocks.
     const unsigned long long total_items = (unsigned long long)npix * (unsigned long long)p->spp;
     // Blocks of kItemBlockLarge for launches that are long enough for their last blocks not to matter (rt_kernels.hpp): the shipped
-    // scan mode without the diagnostic counters, block sums in LDS, >= 147 samples per pixel, >= 2^28 pixel-samples.  RTIOW_LARGE_BLOCK_MIN_ITEMS
+    // scan mode without the diagnostic counters, block sums in LDS, >= 147 samples per pixel (69 for scenes on the small-grid kernel), >= 2^28 pixel-samples.  RTIOW_LARGE_BLOCK_MIN_ITEMS
     // moves the last threshold (tests: 0 = every launch that qualifies otherwise; a huge value = never).
     const int mode_now = (p->flags & RT_FLAG_NO_FILTER) ? 0 : ctx->scan_mode;
     const char *lb_env = getenv("RTIOW_LARGE_BLOCK_MIN_ITEMS");
-    const unsigned long long lb_min = (lb_env && *lb_env) ? strtoull(lb_env, nullptr, 0) : rt::kLargeMinItems;
+    const unsigned long long lb_min = (lb_env && *lb_env) ? strtoull(lb_env, nullptr, 0)
+                                    : (p->flags & RT_FLAG_OVERLAPPED) ? 0ull : rt::kLargeMinItems;   // (overlapped passes: the next pass fills the tail)
+    const bool small_grid_scene = ctx->grid_dim > 0 && ctx->n_global + ctx->grid_dim * ctx->grid_dim <= 64;
     const bool large_blocks = mode_now == 5 && !(p->flags & RT_FLAG_DIAG_STATS) && p->spp >= ctx->ring_min_spp &&
-                              p->spp >= rt::kLargeMinSpp && total_items >= lb_min;
+                              p->spp >= (small_grid_scene ? rt::kLargeMinSppSmallGrid : rt::kLargeMinSpp) && total_items >= lb_min;
     const unsigned item_block = large_blocks ? rt::kItemBlockLarge : rt::kItemBlock;
     const unsigned long long n_blocks = (total_items + item_block - 1) / item_block;
     if (n_blocks > 0x7fffffffULL)
@@ -738,7 +740,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     const int mode = (p->flags & RT_FLAG_NO_FILTER) ? 0 : ctx->scan_mode;
     ctx->last.scan_mode = mode;
     ctx->last.kernel_variant = 0;
-    const bool small_grid = ctx->grid_dim > 0 && ctx->n_global + ctx->grid_dim * ctx->grid_dim <= 64;
+    const bool small_grid = small_grid_scene;
     if (p->flags & RT_FLAG_UNIFORM53) {
         // 53-bit uniforms: instantiated for the shipped scan mode (both grid variants) and for RT_FLAG_NO_FILTER
         if (diag || (mode != 0 && mode != 5))

@@ -97,13 +97,15 @@ constexpr int kBlock = 256;
 constexpr int kCandCap = 24;        // MODE 1: per-lane candidate slots
 constexpr int kScanUnroll = 8;      // MODE 1: spheres per scalar-load batch / overflow check
 constexpr int kItemBlock = 256;     // pixel-samples a wave reserves per atomic on the work counter
-// ... and 1 024 for launches of at least 2^28 pixel-samples at >= 147 samples per pixel (ceil(1023 / 147) + 1 = 8 pixels: still kRingSlots):
+// ... and 1 024 for launches of at least 2^28 pixel-samples at >= 147 samples per pixel (ceil(1023 / 147) + 1 = 8 pixels: still kRingSlots; the
+// small-grid kernel: >= 69 samples per pixel, ceil(1023 / 69) + 1 = 16 pixels, its large blocks' ring has 2 x 16 pixel slots, render_kernel below):
 // reserving a block is a returning atomic the whole wave waits for, and a block's sums are one frame-buffer request per pixel and channel:
 // a quarter of both (1200x675x500: 52.7 -> 51.3 ms; 10k spheres 1920x1080x256: 93.7 -> 91.5 ms).  Smaller launches keep 256: their last
 // blocks are the end-of-launch tail (1200x675x147 is 5 % slower with 1 024).
 constexpr int kItemBlockLarge = 1024;
 static_assert(kItemBlockLarge + 32768 < 65536, "udiv_small: numerators x < d + kItemBlockLarge with d < 2^15 keep x * d < 2^32");
 constexpr int kLargeMinSpp = 147;
+constexpr int kLargeMinSppSmallGrid = 69;
 constexpr unsigned long long kLargeMinItems = 1ull << 28;
 constexpr int kRingSlots = 8;       // pixels a block may touch when its sums are kept in LDS: ceil(255 / spp) + 1 <= 8
 constexpr int kRingMinSpp = 37;     //   ... which holds from 37 spp per launch on; below that samples go to the frame buffer one by one
@@ -167,6 +169,16 @@ template <int MODE, bool DIAG, bool SMALLGRID = false, bool U53 = false, int ITE
 // diagnostic variant and the cross-check modes 2-4 carry 1-14 KB more and run three.
 __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 : 5) void render_kernel(const KParams P)
 {
+    // The block sums' ring (s_ring below) has the same 768 bytes per wave in both shapes: 4 blocks x 8 pixels, or -- the small-grid kernel on
+    // blocks of kItemBlockLarge -- 2 blocks x 16 pixels: a large block lasts ~43 passes, so the one before it has long finished when the
+    // next one begins (a path has at most max_depth bounces; what is still open then goes the orphans' way), and 16 pixel slots let
+    // launches from kLargeMinSppSmallGrid = 69 samples per pixel on take large blocks (ceil(1023 / 69) + 1 = 16).  Measured, interleaved:
+    // 1200x675x500 48.87 -> 48.74 ms; the LARGE-grid kernel is 0.7 % slower with the same change (10k spheres 1920x1080x256: 85.99 ->
+    // 86.58 ms, fewer instructions, another schedule) and keeps 4 x 8 and kLargeMinSpp = 147.
+    constexpr bool kWideRing = ITEMS > kItemBlock && SMALLGRID;
+    constexpr int kRingDepth = kWideRing ? 2 : 4;
+    constexpr int kRingSlots = kWideRing ? 16 : 8;
+    static_assert(kRingDepth * kRingSlots == rt::kRingDepth * rt::kRingSlots, "same LDS either way");
     __shared__ uint16_t cand[MODE == 1 ? kCandCap : 1][MODE == 1 ? kBlock : 1];     // MODE 1: per-lane candidate lists
     constexpr bool MATRIX = (MODE >= 2);
     constexpr bool LIFTED = (MODE == 4);
@@ -248,8 +260,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
     unsigned int *rpix_w = &s_rpix[tid >> 6][0];
     // samples the wave's four youngest blocks still wait for (wave-uniform; index = age: 0 is the current block
     // blk_seq, k is block blk_seq - k, whose sums are ring entry (blk_seq - k) % kRingDepth); 0 = complete or none
-    uint32_t rem0 = 0, rem1 = 0, rem2 = 0, rem3 = 0;
-    static_assert(kRingDepth == 4, "the block counters are written out for a ring of 4");
+    uint32_t rem0 = 0, rem1 = 0, rem2 = 0, rem3 = 0;           // (rem2, rem3: rings of 4 only)
+    static_assert(kRingDepth == 4 || kRingDepth == 2, "the block counters are written out for a ring of 4 or 2");
     // one block's sums -> frame buffer (wave-uniform call; `e` uniform): lane l < 24 holds (pixel slot l/3, channel l%3),
     // which are 24 consecutive u64 of the frame buffer; zero sums (unused slots, black pixels) are not sent
     auto flush_ring = [&](uint32_t e) {
@@ -332,8 +344,13 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                         // The oldest of the four blocks leaves the ring.  If a path of > ~30 bounces still holds it open,
                         // what it has collected goes out now and its remaining samples will go to the frame buffer
                         // directly when they finish ("orphans": their age is then >= kRingDepth).
-                        if (rem3 != 0u) flush_ring(blk_seq & (uint32_t)(kRingDepth - 1));
-                        rem3 = rem2; rem2 = rem1; rem1 = rem0; rem0 = blk_end;
+                        if constexpr (kRingDepth == 4) {
+                            if (rem3 != 0u) flush_ring(blk_seq & (uint32_t)(kRingDepth - 1));
+                            rem3 = rem2; rem2 = rem1; rem1 = rem0; rem0 = blk_end;
+                        } else {
+                            if (rem1 != 0u) flush_ring(blk_seq & (uint32_t)(kRingDepth - 1));
+                            rem1 = rem0; rem0 = blk_end;
+                        }
                         if (lane == 0) rpix_w[blk_seq & (uint32_t)(kRingDepth - 1)] = blk_pix0;
                         __builtin_amdgcn_wave_barrier();
                     }
@@ -1215,8 +1232,14 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 __builtin_amdgcn_wave_barrier();
                 const unsigned long long m0 = __ballot(ringed && age == 0u);
                 rem0 -= (uint32_t)__popcll(m0);
-                if (m0 != 0ull && rem0 == 0u) flush_ring(blk_seq & 3u);
+                if (m0 != 0ull && rem0 == 0u) flush_ring(blk_seq & (uint32_t)(kRingDepth - 1));
                 fm &= ~m0;
+                if constexpr (kRingDepth == 2) {
+                    if (fm != 0ull) {                               // (the rest finished in the block before)
+                        rem1 -= (uint32_t)__popcll(fm);
+                        if (rem1 == 0u) flush_ring((blk_seq - 1u) & 1u);
+                    }
+                } else
                 if (fm != 0ull) {
                     const unsigned long long m1 = __ballot(ringed && age == 1u);
                     rem1 -= (uint32_t)__popcll(m1);
@@ -1240,10 +1263,12 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
     }
     // every block of this wave has finished its last sample and has been written out; a ring entry that
     // still holds something here would be a bookkeeping error -- its sums go out rather than get lost
-    if (rem0 != 0u) flush_ring(blk_seq & 3u);
-    if (rem1 != 0u) flush_ring((blk_seq - 1u) & 3u);
-    if (rem2 != 0u) flush_ring((blk_seq - 2u) & 3u);
-    if (rem3 != 0u) flush_ring((blk_seq - 3u) & 3u);
+    if (rem0 != 0u) flush_ring(blk_seq & (uint32_t)(kRingDepth - 1));
+    if (rem1 != 0u) flush_ring((blk_seq - 1u) & (uint32_t)(kRingDepth - 1));
+    if constexpr (kRingDepth == 4) {
+        if (rem2 != 0u) flush_ring((blk_seq - 2u) & 3u);
+        if (rem3 != 0u) flush_ring((blk_seq - 3u) & 3u);
+    }
 
         // (end of the bounce loop body is stamped at the top of the next iteration as phase 4)
     // wave totals -> device counters

@@ -410,10 +410,11 @@ def test_rays_and_scenes_outside_the_filters_analysed_range(renderer, oracle_mod
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene,w,h,spp,flags", [("book", 160, 90, 150, 0), ("book", 96, 54, 300, rt.RT_FLAG_UNIFORM53),
-                                                  ("3000", 120, 68, 147, 0), ("book", 131, 57, 211, 0)])
+                                                  ("3000", 120, 68, 147, 0), ("book", 131, 57, 211, 0), ("book", 150, 80, 69, 0),
+                                                  ("3000", 97, 61, 100, 0)])
 def test_large_work_blocks_bit_exact(oracle_mod, book1_flat, scene, w, h, spp, flags):
-    """Launches of >= 2^28 pixel-samples at >= 147 samples per pixel hand out work in blocks of 1 024 pixel-samples instead of
-    256 (another instantiation of the kernel: rt_stats.kernel_variant bit 2).  RTIOW_LARGE_BLOCK_MIN_ITEMS=0 selects it for a
+    """Launches of >= 2^28 pixel-samples at >= 69 samples per pixel hand out work in blocks of 1 024 pixel-samples instead of
+    256 (another instantiation of the kernel, whose ring of block sums is 2 blocks x 16 pixels instead of 4 x 8: rt_stats.kernel_variant bit 2).  RTIOW_LARGE_BLOCK_MIN_ITEMS=0 selects it for a
     launch small enough for the oracle: both grid variants, the 53-bit stream, ragged sizes (a last block that is not full,
     blocks that straddle rows), and a second pass with sample_begin -- against Oracle B, bit for bit."""
     if flags & rt.RT_FLAG_UNIFORM53 and os.environ.get("RTIOW_SCAN_MODE", "5") != "5":
@@ -426,14 +427,17 @@ def test_large_work_blocks_bit_exact(oracle_mod, book1_flat, scene, w, h, spp, f
             cam = rt.book1_camera(w, h)
             _, fix, st = r.render(cam, rt.make_params(w, h, spp, flags=flags))
             # (only the shipped scan mode has the large-block instantiations: the cross-check modes run this test on blocks of 256)
-            large = 4 if st["scan_mode"] == 5 else 0
+            # ... from 147 samples per pixel on; the small-grid kernel (kernel_variant bit 0), whose large-block ring has 16 pixel slots, from 69 on
+            large150 = 4 if st["scan_mode"] == 5 else 0
+            large = large150 if (spp >= 147 or (st["kernel_variant"] & 1 and spp >= 69)) else 0
+            assert (scene == "book") == bool(st["kernel_variant"] & 1) or st["scan_mode"] != 5
             assert (st["kernel_variant"] & 4) == large and st["direct_samples"] < st["samples"] // 100
             ocam = oracle_mod.camera_from_host(cam)
             fb, _, stb = oracle_mod.render_b(ocam, flat, oracle_mod.make_params(w, h, spp, uniform53=bool(flags & rt.RT_FLAG_UNIFORM53), nthreads=8))
             assert np.array_equal(fix, fb) and st["rays_traced"] == stb["rays_traced"]
             _, fix2, st2 = r.render(cam, rt.make_params(w, h, 150, sample_begin=1000, flags=flags))
             fb2, _, _ = oracle_mod.render_b(ocam, flat, oracle_mod.make_params(w, h, 150, sample_begin=1000, uniform53=bool(flags & rt.RT_FLAG_UNIFORM53), nthreads=8))
-            assert (st2["kernel_variant"] & 4) == large and np.array_equal(fix2, fb2)
+            assert (st2["kernel_variant"] & 4) == large150 and np.array_equal(fix2, fb2)
         os.environ["RTIOW_LARGE_BLOCK_MIN_ITEMS"] = str(1 << 62)          # never: the same launch on blocks of 256 gives the same frame
         with rt.Renderer(0) as r:
             r.upload_scene(flat)

@@ -11,21 +11,26 @@ import rtiow_amd as rt
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("w,h,spp_pass,passes", [(160, 90, 40, 5), (96, 54, 7, 3), (64, 36, 41, 4)])
-def test_overlapping_passes_on_two_streams_equal_one_oracle_render(renderer, oracle_mod, book1_flat, w, h, spp_pass, passes):
+@pytest.mark.parametrize("w,h,spp_pass,passes,overlapped", [(160, 90, 40, 5, 0), (96, 54, 7, 3, 0), (64, 36, 41, 4, 1), (112, 63, 80, 3, 1),
+                                                            (80, 45, 150, 2, 1)])
+def test_overlapping_passes_on_two_streams_equal_one_oracle_render(renderer, oracle_mod, book1_flat, w, h, spp_pass, passes, overlapped):
     """40/41 spp per pass: block sums in LDS; 7: straight to the frame buffer.  Four and five passes: every slot is reused
-    (the third launch makes its stream wait for the first)."""
+    (the third launch makes its stream wait for the first).  RT_FLAG_OVERLAPPED (the caller says that the passes overlap): work blocks
+    of 1 024 pixel-samples whatever the launch's size, from 69 samples per pixel on (rt_stats.kernel_variant bit 2) -- the same frame."""
     renderer.upload_scene(book1_flat)
     cam = rt.book1_camera(w, h)
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     d_fix = torch.zeros((h, w, 3), dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()                                    # the buffer is zero before any stream adds to it
     for k in range(passes):
-        p = rt.make_params(w, h, spp_pass, sample_begin=k * spp_pass, seed=5, flags=rt.RT_FLAG_ACCUMULATE)
+        p = rt.make_params(w, h, spp_pass, sample_begin=k * spp_pass, seed=5,
+                           flags=rt.RT_FLAG_ACCUMULATE | (rt.RT_FLAG_OVERLAPPED if overlapped else 0))
         renderer.render_device(cam, p, d_fix.data_ptr(), streams[k & 1].cuda_stream)
     torch.cuda.synchronize()
     st = renderer.last_stats()
     assert st["samples"] == w * h * spp_pass                    # (the latest launch)
+    if st["scan_mode"] == 5:
+        assert bool(st["kernel_variant"] & 4) == bool(overlapped and spp_pass >= 69)
     got = d_fix.cpu().numpy().view(np.uint64)
     want, _, _ = oracle_mod.render_b(oracle_mod.camera_from_host(cam), book1_flat, oracle_mod.make_params(w, h, spp_pass * passes, seed=5))
     assert np.array_equal(got, want)
@@ -53,7 +58,7 @@ def test_two_launches_in_flight_keep_their_own_counters(renderer, oracle_mod, bo
 
 def test_cpp_cli_overlapping_passes_write_the_single_calls_image(tmp_path):
     """host/rtiow_render --passes N: the compiled host issues N additive launches alternately on two streams of one context
-    (rt_render_device + RT_FLAG_ACCUMULATE, then rt_resolve_rgba8_device); the image file is the single call's, byte for byte."""
+    (rt_render_device + RT_FLAG_ACCUMULATE | RT_FLAG_OVERLAPPED, then rt_resolve_rgba8_device); the image file is the single call's, byte for byte."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

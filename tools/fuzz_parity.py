@@ -1,7 +1,7 @@
 """Randomised GPU-vs-oracle parity soak (development tool): many random scenes, cameras, image
 sizes and seeds; every frame must equal Oracle B bit for bit.  Usage: fuzz_parity.py [cases] [seed0]
 FUZZ_LARGE=p: share of scenes with enough spheres for a grid of more than 64 cells (default 0.15);
-FUZZ_U53=p: share of cases rendered with RT_FLAG_UNIFORM53 (default 0); FUZZ_HIGH_SPP=p: share of cases with 147..400 samples per
+FUZZ_U53=p: share of cases rendered with RT_FLAG_UNIFORM53 (default 0); FUZZ_HIGH_SPP=p: share of cases with 69..400 samples per
 pixel on a tiny image (with RTIOW_LARGE_BLOCK_MIN_ITEMS=0 those launches use the work blocks of 1 024 pixel-samples)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,7 +42,7 @@ for case in range(cases):
     if rng.random() < 0.3:          # launches of >= 37 spp keep their work blocks' sums in LDS (a different write path)
         W, H, spp = int(rng.integers(6, 28)), int(rng.integers(5, 20)), int(rng.integers(37, 90))
     if rng.random() < float(os.environ.get("FUZZ_HIGH_SPP", "0")):
-        W, H, spp = int(rng.integers(5, 20)), int(rng.integers(4, 14)), int(rng.integers(147, 400))
+        W, H, spp = int(rng.integers(5, 20)), int(rng.integers(4, 14)), int(rng.integers(69, 400))
     lf = rng.uniform(-spread, spread, 3); lf[1] = abs(lf[1]) * 0.3 + 0.3 * spread / 10
     la = rng.uniform(-spread, spread, 3) * 0.3
     cam = rt.Camera(lf, la, rt.Vec3(0, 1, 0), float(rng.uniform(5, 120)), W / H, float(rng.uniform(0.0, 0.5)) * spread / 10,

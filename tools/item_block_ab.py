@@ -1,5 +1,5 @@
 """Diagnostic: kernel time of the same launch on work blocks of 256 and of 1 024 pixel-samples (RTIOW_LARGE_BLOCK_MIN_ITEMS moves the
-threshold of rt_api.hip: 0 = large blocks whenever the launch has >= 147 samples per pixel, a huge value = never), launches interleaved
+threshold of rt_api.hip: 0 = large blocks whenever the launch has >= 147 (small-grid kernel: 69) samples per pixel, a huge value = never), launches interleaved
 in both orders.  usage: python tools/item_block_ab.py"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

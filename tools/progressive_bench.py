@@ -8,6 +8,7 @@ import torch
 import rtiow_amd as rt
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+OVERLAPPED_FLAG = os.environ.get("NO_OVERLAPPED_FLAG") is None      # (NO_OVERLAPPED_FLAG=1: the two-stream passes without RT_FLAG_OVERLAPPED, i.e. on blocks of 256)
 W, H = 1200, 675
 r = rt.Renderer(0)
 r.upload_scene(rt.random_scene(1).flatten())
@@ -23,7 +24,7 @@ def frame(passes, spp_pass, two_streams, spp_list=None):
     b = 0
     for k in range(passes):
         n = spp_list[k] if spp_list else spp_pass
-        p = rt.make_params(W, H, n, sample_begin=b, seed=1, flags=rt.RT_FLAG_ACCUMULATE)
+        p = rt.make_params(W, H, n, sample_begin=b, seed=1, flags=rt.RT_FLAG_ACCUMULATE | (rt.RT_FLAG_OVERLAPPED if two_streams and OVERLAPPED_FLAG else 0))
         r.render_device(cam, p, d_fix.data_ptr(), s[k & 1 if two_streams else 0].cuda_stream)
         b += n
     torch.cuda.synchronize()
