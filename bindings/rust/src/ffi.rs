@@ -34,6 +34,7 @@ pub const RT_FLAG_NO_FILTER: u32 = 0x2;
 pub const RT_FLAG_DIAG_STATS: u32 = 0x4;
 pub const RT_FLAG_UNIFORM53: u32 = 0x8;
 pub const RT_FLAG_OVERLAPPED: u32 = 0x10;
+pub const RT_FLAG_KNOWN: u32 = 0x1f;
 
 /// The two limits of the boundary where the reference's own types are unbounded (include/rtiow_hip.h): the length of
 /// `HittableList` (src/shapes/mod.rs:52) and the pixel sum (src/main.rs:127,135: here exact u64 sums of samples clamped at 2^16).

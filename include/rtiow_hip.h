@@ -120,6 +120,7 @@ typedef struct {
                                     pass fills its end-of-launch tail, so it takes the work blocks of 1 024 pixel-samples whatever its size
                                     (alone, a launch of < 2^28 pixel-samples is up to 6 % slower on them: its last blocks are its tail).
                                     The same frame either way; 2 x 250 spp at 1200x675: 1.045 -> 1.012 x one 500-spp launch */
+#define RT_FLAG_KNOWN      0x1fu /* every other bit of rt_params.flags is an error (RT_ERR_INVALID_ARGUMENT), not ignored */
 
 typedef struct {
     uint64_t samples;            /* pixel-samples finished                          */

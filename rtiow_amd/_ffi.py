@@ -43,6 +43,7 @@ RT_FLAG_NO_FILTER = 0x2
 RT_FLAG_DIAG_STATS = 0x4
 RT_FLAG_UNIFORM53 = 0x8
 RT_FLAG_OVERLAPPED = 0x10
+RT_FLAG_KNOWN = 0x1f
 
 # every symbol include/rtiow_hip.h declares: (name, restype, argtypes)
 _VP = C.c_void_p

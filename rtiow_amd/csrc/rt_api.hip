@@ -114,6 +114,9 @@ int validate_params(const rt_params *p)
     if (p->tile_rows < 1) return fail(RT_ERR_INVALID_ARGUMENT, "tile_rows must be >= 1");
     if (p->shard_count < 1 || p->shard_index < 0 || p->shard_index >= p->shard_count)
         return fail(RT_ERR_INVALID_ARGUMENT, "need 0 <= shard_index < shard_count");
+    // (a bit this library does not know would be a request it silently ignores: a caller built against a newer header finds out here)
+    if (p->flags & ~RT_FLAG_KNOWN)
+        return fail(RT_ERR_INVALID_ARGUMENT, "unknown flags 0x%x (this library knows 0x%x)", p->flags & ~RT_FLAG_KNOWN, RT_FLAG_KNOWN);
     return RT_OK;
 }
 

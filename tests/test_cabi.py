@@ -65,7 +65,7 @@ def test_identity():
     (dict(width=1), "width and height"), (dict(height=1), "width and height"),
     (dict(spp=-1), "spp"), (dict(t_min=0.0), "t_min"), (dict(tile_rows=0), "tile_rows"),
     (dict(shard_index=2, shard_count=2), "shard_index"), (dict(shard_count=0), "shard_index"),
-    (dict(max_depth=-1), "max_depth"),
+    (dict(max_depth=-1), "max_depth"), (dict(flags=0x20), "unknown flags 0x20"), (dict(flags=0x80000001), "unknown flags"),
 ])
 def test_parameter_validation(kw, msg):
     base = dict(width=8, height=8, spp=1)
