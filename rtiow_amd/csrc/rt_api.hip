@@ -93,7 +93,7 @@ struct rt_context {
     void *d_stage_sum = nullptr; size_t stage_sum_bytes = 0;
     void *d_stage_rgba = nullptr; size_t stage_rgba_bytes = 0;
     int blocks_per_cu = 0;     // 0 = occupancy query
-    int ring_min_spp = rt::kRingMinSpp;   // RTIOW_RING_MIN_SPP (diagnostic): spp per launch from which block sums are kept in LDS
+    int ring_min_spp = 0;                 // RTIOW_RING_MIN_SPP (diagnostic): spp per launch from which block sums are kept in LDS (0: the kernel's own minimum)
 };
 
 namespace {
@@ -461,8 +461,7 @@ int rt_create(int32_t device_id, rt_context **out)
     ctx->device = device_id;
     ctx->cu_count = prop.multiProcessorCount;
     ctx->blocks_per_cu = env_int("RTIOW_BLOCKS_PER_CU", 0);
-    ctx->ring_min_spp = env_int("RTIOW_RING_MIN_SPP", rt::kRingMinSpp);
-    if (ctx->ring_min_spp < rt::kRingMinSpp) ctx->ring_min_spp = rt::kRingMinSpp;     // fewer would overrun the 8 pixel slots
+    ctx->ring_min_spp = env_int("RTIOW_RING_MIN_SPP", 0);                             // (raised to the kernel's own minimum per launch)
     ctx->scan_mode = env_int("RTIOW_SCAN_MODE", 5);
 #ifdef RTIOW_CROSSCHECK_MODES
     if (ctx->scan_mode < 1 || ctx->scan_mode > 5) ctx->scan_mode = 5;
@@ -666,9 +665,20 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     const unsigned long long lb_min = (lb_env && *lb_env) ? strtoull(lb_env, nullptr, 0)
                                     : (p->flags & RT_FLAG_OVERLAPPED) ? 0ull : rt::kLargeMinItems;   // (overlapped passes: the next pass fills the tail)
     const bool small_grid_scene = ctx->grid_dim > 0 && ctx->n_global + ctx->grid_dim * ctx->grid_dim <= 64;
-    const bool large_blocks = mode_now == 5 && !(p->flags & RT_FLAG_DIAG_STATS) && p->spp >= ctx->ring_min_spp &&
+    // Block sums in LDS: a block's consecutive samples must touch no more pixels than its sums have slots -- ceil((items - 1) / spp) + 1 <= 8,
+    // or 16 on the small-grid kernel --: blocks of 256 from 37 (17) samples per pixel on, and below that the largest multiple of 64 (a block
+    // is started 64 samples at a time) that fits: 192, 128 or 64 pixel-samples, down to 9 (5) samples per pixel.  Fewer: every sample is added
+    // to the frame buffer with three 64-bit atomics of its own -- a quarter of the frame time at 20-32 samples per pixel (1200x675x32: 5.46 ms
+    // that way, 4.04 ms with block sums).  RTIOW_RING_MIN_SPP=n (tests): no block sums below n samples per pixel.
+    const bool wide_ring = mode_now == 5 && !(p->flags & RT_FLAG_DIAG_STATS) && small_grid_scene;
+    const unsigned ring_slots = wide_ring ? 2u * (unsigned)rt::kRingSlots : (unsigned)rt::kRingSlots;
+    unsigned small_block = 0;
+    for (unsigned items = rt::kItemBlock; items >= 64u && p->spp >= 1; items -= 64u)
+        if ((items - 1u + (unsigned)p->spp - 1u) / (unsigned)p->spp + 1u <= ring_slots) { small_block = items; break; }
+    const bool use_ring = small_block != 0u && p->spp >= ctx->ring_min_spp;
+    const bool large_blocks = mode_now == 5 && !(p->flags & RT_FLAG_DIAG_STATS) && use_ring && small_block == (unsigned)rt::kItemBlock &&
                               p->spp >= (small_grid_scene ? rt::kLargeMinSppSmallGrid : rt::kLargeMinSpp) && total_items >= lb_min;
-    const unsigned item_block = large_blocks ? rt::kItemBlockLarge : rt::kItemBlock;
+    const unsigned item_block = large_blocks ? rt::kItemBlockLarge : use_ring ? small_block : rt::kItemBlock;
     const unsigned long long n_blocks = (total_items + item_block - 1) / item_block;
     if (n_blocks > 0x7fffffffULL)
         return fail(RT_ERR_INVALID_ARGUMENT, "rows*width*spp = %llu pixel-samples in one launch: at most 2^31 blocks of %d "
@@ -692,8 +702,8 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
         return (d <= 1 || d >= 32768) ? 0u : (uint32_t)(0x100000000ULL / (unsigned long long)d + 1ULL);
     };
     kp.magic_spp = magic_for(p->spp); kp.magic_width = magic_for(p->width); kp.magic_tile = magic_for(p->tile_rows);
-    // a block of kItemBlock consecutive samples touches at most ceil((kItemBlock-1)/spp) + 1 pixels: kRingSlots from 37 spp on
-    kp.use_ring = p->spp >= ctx->ring_min_spp ? 1 : 0;
+    kp.use_ring = use_ring ? 1 : 0;
+    kp.block_items = item_block;
     kp.filt = ctx->d_filt; kp.geo = ctx->d_geo; kp.mat = ctx->d_mat;
     kp.n_tiles = ctx->n_tiles;
 #ifdef RTIOW_CROSSCHECK_MODES

@@ -57,16 +57,17 @@ struct KParams {
     int32_t tile_rows, shard_index, shard_count;
     int32_t rows;              // compact rows of this shard
     int32_t n_spheres;
-    int32_t use_ring;          // 1: per-wave LDS block sums (spp >= kRingMinSpp); 0: every sample goes to the frame buffer directly
+    int32_t use_ring;          // 1: per-wave LDS block sums (whenever a block's pixels fit the ring's pixel slots: rt_api.hip picks block_items for that); 0: every sample goes to the frame buffer directly
     uint32_t npix;             // rows * width
-    uint32_t n_blocks;         // work blocks of ITEMS consecutive pixel-samples, pixel-major: item w = pixel * spp + sample
+    uint32_t n_blocks;         // work blocks of block_items consecutive pixel-samples, pixel-major: item w = pixel * spp + sample
     unsigned long long total_items;   // npix * spp
     double inv_spp;            // 1.0 / spp (block -> first pixel)
     double inv_width;          // 1.0 / width (first pixel -> row, column)
     // per-lane divisions of small numerators by launch constants, as multiply-high (udiv_small below):
     // floor(2^32 / d) + 1 for d = spp, width, tile_rows (unused where d == 1 or d >= 2^16)
     uint32_t magic_spp, magic_width, magic_tile;
-    uint32_t pad_magic;
+    uint32_t block_items;      // pixel-samples per work block: ITEMS, or -- launches of few samples per pixel -- the multiple of 64 below it whose pixels
+                               // still fit the ring's pixel slots (rt_api.hip)
     const float *filt;         // [n][4]  f32 filter record (cx, cy, cz, K')
 #ifdef RTIOW_CROSSCHECK_MODES
     KXcheckTables x;           // the B operands of scan modes 2-4 (xcheck/rt_xcheck_params.hpp)
@@ -107,9 +108,10 @@ static_assert(kItemBlockLarge + 32768 < 65536, "udiv_small: numerators x < d + k
 constexpr int kLargeMinSpp = 147;
 constexpr int kLargeMinSppSmallGrid = 69;
 constexpr unsigned long long kLargeMinItems = 1ull << 28;
-constexpr int kRingSlots = 8;       // pixels a block may touch when its sums are kept in LDS: ceil(255 / spp) + 1 <= 8
-constexpr int kRingMinSpp = 37;     //   ... which holds from 37 spp per launch on; below that samples go to the frame buffer one by one
+constexpr int kRingSlots = 8;       // pixels a block may touch when its sums are kept in LDS: ceil((block_items - 1) / spp) + 1 <= 8 -- blocks of 256 from
+                                    //   37 spp per launch on, of 192 / 128 / 64 down to 9 spp (rt_api.hip); below that samples go to the frame buffer one by one
 constexpr int kRingDepth = 4;       // blocks of one wave that may be unfinished at the same time (older ones: see `orphan`)
+                                    //   (the small-grid kernel: 2 blocks x 16 pixels, render_kernel below: blocks of 256 from 17 spp on, sums down to 5 spp)
 constexpr int kMatStride = 10;      // doubles per material record
 constexpr int kListCap = 126;       // MODE 5: longest list of tiles a wave scans by list; beyond, it scans the whole table
 constexpr int kSegTilesTube = 28;   // MODE 5: 14 bitmap words of 32 columns per segment (a wave's list is 5-13 tiles long)
@@ -169,13 +171,15 @@ template <int MODE, bool DIAG, bool SMALLGRID = false, bool U53 = false, int ITE
 // diagnostic variant and the cross-check modes 2-4 carry 1-14 KB more and run three.
 __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 : 5) void render_kernel(const KParams P)
 {
-    // The block sums' ring (s_ring below) has the same 768 bytes per wave in both shapes: 4 blocks x 8 pixels, or -- the small-grid kernel on
-    // blocks of kItemBlockLarge -- 2 blocks x 16 pixels: a large block lasts ~43 passes, so the one before it has long finished when the
-    // next one begins (a path has at most max_depth bounces; what is still open then goes the orphans' way), and 16 pixel slots let
-    // launches from kLargeMinSppSmallGrid = 69 samples per pixel on take large blocks (ceil(1023 / 69) + 1 = 16).  Measured, interleaved:
-    // 1200x675x500 48.87 -> 48.74 ms; the LARGE-grid kernel is 0.7 % slower with the same change (10k spheres 1920x1080x256: 85.99 ->
-    // 86.58 ms, fewer instructions, another schedule) and keeps 4 x 8 and kLargeMinSpp = 147.
-    constexpr bool kWideRing = ITEMS > kItemBlock && SMALLGRID;
+    // The block sums' ring (s_ring below) has the same 768 bytes per wave in both shapes: 4 blocks x 8 pixels, or -- the small-grid kernel
+    // (scan mode 5, grids of <= 64 cells) -- 2 blocks x 16 pixels.  Two blocks in flight are enough: a block of 256 lasts ~11 passes, one of
+    // 1 024 ~43, and the samples of the block before the previous one that are still open when a block begins (paths of more than
+    // ~15 / ~50 bounces: ~1 in 10^3 / none) go the orphans' way; two counters instead of four, a shorter cascade when samples finish.  And 16
+    // pixel slots let launches from 17 samples per pixel on keep the sums of blocks of 256 in LDS (ceil(255 / 17) + 1 = 16; smaller blocks: from 5) and
+    // launches from kLargeMinSppSmallGrid = 69 on take large blocks (ceil(1023 / 69) + 1 = 16).  Measured, interleaved: 1200x675x500 48.87 ->
+    // 48.74 ms, 1200x675x100 10.53 -> 10.49 ms; the LARGE-grid kernel is 0.7 % slower with the same ring (10k spheres 1920x1080x256:
+    // 85.99 -> 86.58 ms, fewer instructions, another schedule) and keeps 4 x 8 (blocks of 256 from 37 spp on) and kLargeMinSpp = 147.
+    constexpr bool kWideRing = SMALLGRID;
     constexpr int kRingDepth = kWideRing ? 2 : 4;
     constexpr int kRingSlots = kWideRing ? 16 : 8;
     static_assert(kRingDepth * kRingSlots == rt::kRingDepth * rt::kRingSlots, "same LDS either way");
@@ -324,9 +328,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                         break;
                     }
                     // first item of the block -> (pixel, sample): W0 / spp in f64 (W0 < 2^39: exact), one correction step
-                    const unsigned long long W0 = (unsigned long long)nb * (unsigned long long)ITEMS;
+                    const unsigned long long W0 = (unsigned long long)nb * (unsigned long long)P.block_items;     // (block_items <= ITEMS)
                     const unsigned long long left = P.total_items - W0;
-                    const uint32_t n_items = left < (unsigned long long)ITEMS ? (uint32_t)left : (uint32_t)ITEMS;
+                    const uint32_t n_items = left < (unsigned long long)P.block_items ? (uint32_t)left : P.block_items;
                     uint32_t p0 = (uint32_t)((double)W0 * P.inv_spp);
                     long long rem = (long long)(W0 - (unsigned long long)p0 * (unsigned long long)(uint32_t)P.spp);
                     if (rem < 0) { p0 -= 1u; rem += (long long)P.spp; }
@@ -1218,7 +1222,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 
                 if (ringed) {
                     unsigned long long *acc = ring_w + ((my_blk >> 4) & (uint32_t)(kRingDepth - 1)) * (kRingSlots * 3) + (my_blk & 15u) * 3u;
                     atomicAdd(acc + 0, q0); atomicAdd(acc + 1, q1); atomicAdd(acc + 2, q2);
-                } else {                                            // spp < kRingMinSpp, or an orphan of a long-gone block
+                } else {                                            // too few samples per pixel for block sums, or an orphan of a long-gone block
                     unsigned long long *px = P.fix + (size_t)pix_local * 3u;
                     atomicAdd(px + 0, q0); atomicAdd(px + 1, q1); atomicAdd(px + 2, q2);
                 }

@@ -39,8 +39,8 @@ for case in range(cases):
         w.push(rt.Sphere(c, rad, m))
     flat = w.flatten()
     W, H, spp = int(rng.integers(8, 64)), int(rng.integers(6, 48)), int(rng.integers(1, 5))
-    if rng.random() < 0.3:          # launches of >= 37 spp keep their work blocks' sums in LDS (a different write path)
-        W, H, spp = int(rng.integers(6, 28)), int(rng.integers(5, 20)), int(rng.integers(37, 90))
+    if rng.random() < 0.4:          # launches of >= 5 / 9 spp keep their work blocks' sums in LDS (a different write path; blocks of 64 .. 256 pixel-samples)
+        W, H, spp = int(rng.integers(6, 28)), int(rng.integers(5, 20)), int(rng.integers(5, 90))
     if rng.random() < float(os.environ.get("FUZZ_HIGH_SPP", "0")):
         W, H, spp = int(rng.integers(5, 20)), int(rng.integers(4, 14)), int(rng.integers(69, 400))
     lf = rng.uniform(-spread, spread, 3); lf[1] = abs(lf[1]) * 0.3 + 0.3 * spread / 10
