@@ -140,7 +140,7 @@ typedef struct {
     uint64_t live_per_bounce[64]; /* rays traced at bounce index k (0 = camera ray; indices >= 63 share the
                                     last slot); sums to rays_traced (RT_FLAG_DIAG_STATS, else 0) */
     uint64_t direct_samples;     /* samples added to the frame buffer one by one instead of through their block's
-                                    sums: all of them in a launch of < 9 spp (< 5 on the small-grid kernel), else only the last samples of blocks
+                                    sums: all of them in a launch of < 5 spp (< 9 with RT_FLAG_NO_FILTER / RT_FLAG_DIAG_STATS), else only the last samples of blocks
                                     that a long path held open for too long (more than ~30 bounces at >= 37 spp, ~15 on the small-grid
                                     kernel; a few bounces on the 64-sample work blocks of launches with < 13 spp) */
 } rt_stats;
@@ -152,7 +152,7 @@ typedef struct {
  *   RTIOW_NO_GRID=1, RTIOW_GRID_DIM=G   rt_upload_scene: no tile grid / G x G cells instead of the cost model's choice
  *   RTIOW_BLOCKS_PER_CU=k          rt_create: workgroups per CU of the persistent grid (default: the occupancy query)
  *   RTIOW_RING_MIN_SPP=n           rt_create: no per-block pixel sums in LDS below n samples per pixel (default: wherever a block's pixels fit the sums' slots,
- *                                  i.e. from 9 samples per pixel on, 5 on the small-grid kernel)
+ *                                  i.e. from 5 samples per pixel on; 9 with RT_FLAG_NO_FILTER / RT_FLAG_DIAG_STATS)
  *   RTIOW_LARGE_BLOCK_MIN_ITEMS=n  per launch: work blocks of 1 024 pixel-samples instead of 256 from n pixel-samples per launch on
  *                                  (default 2^28; also needs >= 147 samples per pixel, 69 on the small-grid kernel; rt_stats.kernel_variant bit 2 says which ran) */
 

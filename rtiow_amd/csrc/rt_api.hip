@@ -666,11 +666,14 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
                                     : (p->flags & RT_FLAG_OVERLAPPED) ? 0ull : rt::kLargeMinItems;   // (overlapped passes: the next pass fills the tail)
     const bool small_grid_scene = ctx->grid_dim > 0 && ctx->n_global + ctx->grid_dim * ctx->grid_dim <= 64;
     // Block sums in LDS: a block's consecutive samples must touch no more pixels than its sums have slots -- ceil((items - 1) / spp) + 1 <= 8,
-    // or 16 on the small-grid kernel --: blocks of 256 from 37 (17) samples per pixel on, and below that the largest multiple of 64 (a block
+    // or 16 on the shipped scan mode's kernels --: blocks of 256 from 37 (17) samples per pixel on, and below that the largest multiple of 64 (a block
     // is started 64 samples at a time) that fits: 192, 128 or 64 pixel-samples, down to 9 (5) samples per pixel.  Fewer: every sample is added
     // to the frame buffer with three 64-bit atomics of its own -- a quarter of the frame time at 20-32 samples per pixel (1200x675x32: 5.46 ms
     // that way, 4.04 ms with block sums).  RTIOW_RING_MIN_SPP=n (tests): no block sums below n samples per pixel.
-    const bool wide_ring = mode_now == 5 && !(p->flags & RT_FLAG_DIAG_STATS) && small_grid_scene;
+    // (the large-grid kernel's instantiation for blocks of 1 024 keeps 4 x 8: a launch that will take large blocks is sized for 8 slots)
+    const bool shipped_kernel = mode_now == 5 && !(p->flags & RT_FLAG_DIAG_STATS);
+    const bool large_candidate = shipped_kernel && !small_grid_scene && p->spp >= rt::kLargeMinSpp && total_items >= lb_min && p->spp >= ctx->ring_min_spp;
+    const bool wide_ring = shipped_kernel && !large_candidate;
     const unsigned ring_slots = wide_ring ? 2u * (unsigned)rt::kRingSlots : (unsigned)rt::kRingSlots;
     unsigned small_block = 0;
     for (unsigned items = rt::kItemBlock; items >= 64u && p->spp >= 1; items -= 64u)

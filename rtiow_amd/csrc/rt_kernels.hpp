@@ -111,7 +111,7 @@ constexpr unsigned long long kLargeMinItems = 1ull << 28;
 constexpr int kRingSlots = 8;       // pixels a block may touch when its sums are kept in LDS: ceil((block_items - 1) / spp) + 1 <= 8 -- blocks of 256 from
                                     //   37 spp per launch on, of 192 / 128 / 64 down to 9 spp (rt_api.hip); below that samples go to the frame buffer one by one
 constexpr int kRingDepth = 4;       // blocks of one wave that may be unfinished at the same time (older ones: see `orphan`)
-                                    //   (the small-grid kernel: 2 blocks x 16 pixels, render_kernel below: blocks of 256 from 17 spp on, sums down to 5 spp)
+                                    //   (the shipped scan mode's kernels: 2 blocks x 16 pixels, render_kernel below: blocks of 256 from 17 spp on, sums down to 5 spp)
 constexpr int kMatStride = 10;      // doubles per material record
 constexpr int kListCap = 126;       // MODE 5: longest list of tiles a wave scans by list; beyond, it scans the whole table
 constexpr int kSegTilesTube = 28;   // MODE 5: 14 bitmap words of 32 columns per segment (a wave's list is 5-13 tiles long)
@@ -171,15 +171,16 @@ template <int MODE, bool DIAG, bool SMALLGRID = false, bool U53 = false, int ITE
 // diagnostic variant and the cross-check modes 2-4 carry 1-14 KB more and run three.
 __global__ __launch_bounds__(kBlock, (MODE == 5 && !DIAG) ? 4 : (MODE >= 2) ? 3 : 5) void render_kernel(const KParams P)
 {
-    // The block sums' ring (s_ring below) has the same 768 bytes per wave in both shapes: 4 blocks x 8 pixels, or -- the small-grid kernel
-    // (scan mode 5, grids of <= 64 cells) -- 2 blocks x 16 pixels.  Two blocks in flight are enough: a block of 256 lasts ~11 passes, one of
+    // The block sums' ring (s_ring below) has the same 768 bytes per wave in both shapes: 4 blocks x 8 pixels, or -- the shipped scan mode's
+    // kernels, all but the large-grid kernel's instantiation for blocks of 1 024 -- 2 blocks x 16 pixels.  Two blocks in flight are enough: a block of 256 lasts ~11 passes, one of
     // 1 024 ~43, and the samples of the block before the previous one that are still open when a block begins (paths of more than
     // ~15 / ~50 bounces: ~1 in 10^3 / none) go the orphans' way; two counters instead of four, a shorter cascade when samples finish.  And 16
     // pixel slots let launches from 17 samples per pixel on keep the sums of blocks of 256 in LDS (ceil(255 / 17) + 1 = 16; smaller blocks: from 5) and
     // launches from kLargeMinSppSmallGrid = 69 on take large blocks (ceil(1023 / 69) + 1 = 16).  Measured, interleaved: 1200x675x500 48.87 ->
-    // 48.74 ms, 1200x675x100 10.53 -> 10.49 ms; the LARGE-grid kernel is 0.7 % slower with the same ring (10k spheres 1920x1080x256:
-    // 85.99 -> 86.58 ms, fewer instructions, another schedule) and keeps 4 x 8 (blocks of 256 from 37 spp on) and kLargeMinSpp = 147.
-    constexpr bool kWideRing = SMALLGRID;
+    // 48.74 ms, 1200x675x100 10.53 -> 10.49 ms, 10k spheres 1920x1080 x20 7.78 -> 7.50 ms, x100 34.98 -> 34.88 ms; the large-grid kernel ON LARGE
+    // BLOCKS is 0.7 % slower with the same ring (10k spheres 1920x1080x256: 85.99 -> 86.58 ms, fewer instructions, another schedule) and
+    // keeps 4 x 8 and kLargeMinSpp = 147.  The cross-check scan modes and the diagnostic-counter kernels keep 4 x 8 too.
+    constexpr bool kWideRing = SMALLGRID || (MODE == 5 && !DIAG && ITEMS == kItemBlock);
     constexpr int kRingDepth = kWideRing ? 2 : 4;
     constexpr int kRingSlots = kWideRing ? 16 : 8;
     static_assert(kRingDepth * kRingSlots == rt::kRingDepth * rt::kRingSlots, "same LDS either way");

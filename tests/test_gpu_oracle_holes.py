@@ -37,15 +37,15 @@ def oracle_frame(oracle_mod, flat, cam, w, h, spp, **kw):
 @pytest.mark.parametrize("begin,spp", [(37, 63), (5, 20), (9, 12), (3, 7), (11, 4), (1000003, 41)])
 def test_sample_begin_vs_oracle(renderer, oracle_mod, book1_flat, begin, spp):
     """One launch that starts at sample `begin`: (37, 63) keeps block sums in LDS on work blocks of 256 pixel-samples, (5, 20) and
-    (9, 12) on smaller blocks (192 / 128 / 64: what fits the ring's pixel slots), (3, 7) only on the small-grid kernel (16 pixel slots:
-    from 5 spp on; the general kernel's 8: from 9), (11, 4) sends every sample to the frame buffer directly, the last has a large first index."""
+    (9, 12) on smaller blocks (192 / 128 / 64: what fits the ring's pixel slots), (3, 7) only on the shipped scan mode's kernels (16 pixel slots:
+    from 5 spp on; the others' 8: from 9), (11, 4) sends every sample to the frame buffer directly, the last has a large first index."""
     w, h = 160, 90
     renderer.upload_scene(book1_flat)
     cam = rt.book1_camera(w, h)
     _, fix, st = renderer.render(cam, rt.make_params(w, h, spp, sample_begin=begin))
     fb, stb = oracle_frame(oracle_mod, book1_flat, cam, w, h, spp, sample_begin=begin)
     assert np.array_equal(fix, fb) and st["rays_traced"] == stb["rays_traced"]
-    assert (st["direct_samples"] == st["samples"]) == (spp < (5 if st["kernel_variant"] & 1 else 9))
+    assert (st["direct_samples"] == st["samples"]) == (spp < (5 if st["scan_mode"] == 5 else 9))
 
 
 @pytest.mark.parametrize("passes", [((0, 60), (60, 40)), ((0, 10), (10, 27), (37, 63)), ((0, 99), (99, 1))])

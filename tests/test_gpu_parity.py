@@ -257,16 +257,16 @@ def test_random_scenes_and_cameras_bit_exact(renderer, oracle_mod, case):
                                      (51, 29, 31), (97, 55, 5), (90, 51, 8), (83, 47, 9), (80, 45, 10), (71, 40, 13), (64, 36, 16), (57, 33, 36)])
 def test_block_sums_in_lds_bit_exact(renderer, oracle_mod, book1_flat, w, h, spp):
     """A wave keeps the sums of its work blocks (256 consecutive pixel-samples, pixel-major) in LDS and writes a block to the frame
-    buffer once.  A block's pixels must fit the ring's pixel slots -- 8, or 16 on the small-grid kernel, the one the book scene runs on --:
+    buffer once.  A block's pixels must fit the ring's pixel slots -- 16 on the shipped scan mode's kernels, 8 on the others --:
     blocks of 256 from 37 / 17 samples per pixel on, of 192, 128 or 64 below that, down to 9 / 5 samples per pixel.  Sizes chosen so that
     blocks start and end in the middle of pixels and rows (spp not a divisor of 256, odd widths, a last
     block of fewer than 256 items)."""
     (sm, fix, st), (fb, sb, stb), _ = both(renderer, oracle_mod, book1_flat, w, h, spp)
     assert np.array_equal(fix, fb) and np.array_equal(sm, sb)
     assert st["rays_traced"] == stb["rays_traced"] and st["samples"] == w * h * spp
-    if spp >= (17 if st["kernel_variant"] & 1 else 37):
+    if spp >= (17 if st["scan_mode"] == 5 else 37):
         assert st["direct_samples"] < st["samples"] // 100       # (orphans of long paths only)
-    elif spp >= (5 if st["kernel_variant"] & 1 else 9):
+    elif spp >= (5 if st["scan_mode"] == 5 else 9):
         assert st["direct_samples"] < st["samples"] // 3         # (small blocks leave the ring sooner: paths of more than a few bounces)
     else:
         assert st["direct_samples"] == st["samples"]             # (the cross-check scan modes run on the general kernel: 8 pixel slots)
@@ -278,8 +278,9 @@ def test_small_spp_goes_to_the_frame_buffer_directly(renderer, oracle_mod, book1
 
 
 def test_ring_minimum_follows_the_kernel(oracle_mod, book1_flat):
-    """6 samples per pixel: block sums in LDS on the small-grid kernel (16 pixel slots: 64 consecutive samples touch 12 pixels), straight to
-    the frame buffer on the general one (8 slots: from 9 on) -- the same scene without its grid (RTIOW_NO_GRID=1) -- and the same frame."""
+    """6 samples per pixel: block sums in LDS on the shipped scan mode's kernels (16 pixel slots: 64 consecutive samples touch 12 pixels) --
+    small grid, and the general kernel: the same scene without its grid (RTIOW_NO_GRID=1) --, straight to the frame buffer on the
+    unfiltered scan's kernel (RT_FLAG_NO_FILTER; 8 slots: from 9 on); the same frame."""
     w, h, spp = 80, 45, 6
     cam = rt.book1_camera(w, h)
     fb, _, _ = oracle_mod.render_b(oracle_mod.camera_from_host(cam), book1_flat, oracle_mod.make_params(w, h, spp))
@@ -296,7 +297,13 @@ def test_ring_minimum_follows_the_kernel(oracle_mod, book1_flat):
             _, fix2, st2 = r.render(cam, rt.make_params(w, h, spp))
     finally:
         os.environ.pop("RTIOW_NO_GRID")
-    assert not (st2["kernel_variant"] & 1) and st2["direct_samples"] == st2["samples"] and np.array_equal(fix2, fb)
+    assert not (st2["kernel_variant"] & 1) and np.array_equal(fix2, fb)
+    if st2["scan_mode"] == 5:
+        assert st2["direct_samples"] < st2["samples"] // 3
+    with rt.Renderer(0) as r:
+        r.upload_scene(book1_flat)
+        _, fix3, st3 = r.render(cam, rt.make_params(w, h, spp, flags=rt.RT_FLAG_NO_FILTER))
+    assert st3["scan_mode"] == 0 and st3["direct_samples"] == st3["samples"] and np.array_equal(fix3, fb)
 
 
 def test_hall_of_mirrors_runs_paths_to_the_depth_limit(renderer, oracle_mod):
