@@ -118,7 +118,7 @@ typedef struct {
                                     RT_FLAG_NO_FILTER, not with RT_FLAG_DIAG_STATS */
 #define RT_FLAG_OVERLAPPED 0x10u /* rt_render_device: this launch is one of a sequence of passes that OVERLAP on two streams (below): the next
                                     pass fills its end-of-launch tail, so it takes the work blocks of 1 024 pixel-samples whatever its size
-                                    (alone, a launch of < 2^28 pixel-samples is up to 6 % slower on them: its last blocks are its tail).
+                                    (alone, a launch of < 2 x 10^8 pixel-samples is up to 6 % slower on them: its last blocks are its tail).
                                     The same frame either way; 2 x 250 spp at 1200x675: 1.045 -> 1.012 x one 500-spp launch */
 #define RT_FLAG_KNOWN      0x1fu /* every other bit of rt_params.flags is an error (RT_ERR_INVALID_ARGUMENT), not ignored */
 
@@ -136,7 +136,7 @@ typedef struct {
     int32_t  kernel_variant;     /* which instantiation of the kernel ran, as bits: 1 the scan_mode-5 kernel for scenes whose
                                     tile grid has <= 64 cells (else the general one, and every other scan mode); 2 the
                                     RT_FLAG_UNIFORM53 instantiation; 4 work blocks of 1 024 pixel-samples instead of 256 (launches of
-                                    >= 2^28 pixel-samples at >= 147 samples per pixel; >= 69 on the small-grid kernel) */
+                                    >= 2 x 10^8 pixel-samples at >= 147 samples per pixel; >= 69 on the small-grid kernel) */
     uint64_t live_per_bounce[64]; /* rays traced at bounce index k (0 = camera ray; indices >= 63 share the
                                     last slot); sums to rays_traced (RT_FLAG_DIAG_STATS, else 0) */
     uint64_t direct_samples;     /* samples added to the frame buffer one by one instead of through their block's
@@ -154,7 +154,7 @@ typedef struct {
  *   RTIOW_RING_MIN_SPP=n           rt_create: no per-block pixel sums in LDS below n samples per pixel (default: wherever a block's pixels fit the sums' slots,
  *                                  i.e. from 5 samples per pixel on; 9 with RT_FLAG_NO_FILTER / RT_FLAG_DIAG_STATS)
  *   RTIOW_LARGE_BLOCK_MIN_ITEMS=n  per launch: work blocks of 1 024 pixel-samples instead of 256 from n pixel-samples per launch on
- *                                  (default 2^28; also needs >= 147 samples per pixel, 69 on the small-grid kernel; rt_stats.kernel_variant bit 2 says which ran) */
+ *                                  (default 2 x 10^8; also needs >= 147 samples per pixel, 69 on the small-grid kernel; rt_stats.kernel_variant bit 2 says which ran) */
 
 /* ---- lifetime -------------------------------------------------------------- */
 

@@ -658,7 +658,7 @@ int rt_render_device(rt_context *ctx, const rt_camera *cam, const rt_params *p, 
     // blocks of kItemBlock consecutive items; the work counter counts blocks.
     const unsigned long long total_items = (unsigned long long)npix * (unsigned long long)p->spp;
     // Blocks of kItemBlockLarge for launches that are long enough for their last blocks not to matter (rt_kernels.hpp): the shipped
-    // scan mode without the diagnostic counters, block sums in LDS, >= 147 samples per pixel (69 for scenes on the small-grid kernel), >= 2^28 pixel-samples.  RTIOW_LARGE_BLOCK_MIN_ITEMS
+    // scan mode without the diagnostic counters, block sums in LDS, >= 147 samples per pixel (69 for scenes on the small-grid kernel), >= 2 x 10^8 pixel-samples.  RTIOW_LARGE_BLOCK_MIN_ITEMS
     // moves the last threshold (tests: 0 = every launch that qualifies otherwise; a huge value = never).
     const int mode_now = (p->flags & RT_FLAG_NO_FILTER) ? 0 : ctx->scan_mode;
     const char *lb_env = getenv("RTIOW_LARGE_BLOCK_MIN_ITEMS");

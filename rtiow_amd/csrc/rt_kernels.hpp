@@ -98,7 +98,7 @@ constexpr int kBlock = 256;
 constexpr int kCandCap = 24;        // MODE 1: per-lane candidate slots
 constexpr int kScanUnroll = 8;      // MODE 1: spheres per scalar-load batch / overflow check
 constexpr int kItemBlock = 256;     // pixel-samples a wave reserves per atomic on the work counter
-// ... and 1 024 for launches of at least 2^28 pixel-samples at >= 147 samples per pixel (ceil(1023 / 147) + 1 = 8 pixels: still kRingSlots; the
+// ... and 1 024 for launches of at least 2 x 10^8 pixel-samples at >= 147 samples per pixel (ceil(1023 / 147) + 1 = 8 pixels: still kRingSlots; the
 // small-grid kernel: >= 69 samples per pixel, ceil(1023 / 69) + 1 = 16 pixels, its large blocks' ring has 2 x 16 pixel slots, render_kernel below):
 // reserving a block is a returning atomic the whole wave waits for, and a block's sums are one frame-buffer request per pixel and channel:
 // a quarter of both (1200x675x500: 52.7 -> 51.3 ms; 10k spheres 1920x1080x256: 93.7 -> 91.5 ms).  Smaller launches keep 256: their last
@@ -107,7 +107,7 @@ constexpr int kItemBlockLarge = 1024;
 static_assert(kItemBlockLarge + 32768 < 65536, "udiv_small: numerators x < d + kItemBlockLarge with d < 2^15 keep x * d < 2^32");
 constexpr int kLargeMinSpp = 147;
 constexpr int kLargeMinSppSmallGrid = 69;
-constexpr unsigned long long kLargeMinItems = 1ull << 28;
+constexpr unsigned long long kLargeMinItems = 200000000ull;   // (1200x675: blocks of 1 024 against 256 at 150 / 200 / 250 / 300 / 350 spp: +3.5 / -0.5 / -1.9 / -2.2 / -2.5 %)
 constexpr int kRingSlots = 8;       // pixels a block may touch when its sums are kept in LDS: ceil((block_items - 1) / spp) + 1 <= 8 -- blocks of 256 from
                                     //   37 spp per launch on, of 192 / 128 / 64 down to 9 spp (rt_api.hip); below that samples go to the frame buffer one by one
 constexpr int kRingDepth = 4;       // blocks of one wave that may be unfinished at the same time (older ones: see `orphan`)

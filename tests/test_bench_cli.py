@@ -21,7 +21,7 @@ def test_self_launch_command_is_a_torchrun_child_on_loopback():
 def test_kernel_name_carries_all_four_template_arguments():
     """roofline.kernel must join with rocprofv3's kernel trace by name: render_kernel<MODE, DIAG, SMALLGRID, U53, ITEMS>."""
     assert bench.kernel_name(5, 1) == "rt::render_kernel<5, false, true, false, 256>"       # the shipped small-grid kernel
-    assert bench.kernel_name(5, 5) == "rt::render_kernel<5, false, true, false, 1024>"      # ... on a launch of >= 2^28 pixel-samples (the bench default)
+    assert bench.kernel_name(5, 5) == "rt::render_kernel<5, false, true, false, 1024>"      # ... on a launch of >= 2 x 10^8 pixel-samples (the bench default)
     assert bench.kernel_name(5, 4) == "rt::render_kernel<5, false, false, false, 1024>"     # large grids (10k spheres, 1920x1080x256)
     assert bench.kernel_name(5, 3) == "rt::render_kernel<5, false, true, true, 256>"        # RT_FLAG_UNIFORM53
     assert bench.kernel_name(0, 2) == "rt::render_kernel<0, false, false, true, 256>"

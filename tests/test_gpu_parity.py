@@ -449,7 +449,7 @@ def test_rays_and_scenes_outside_the_filters_analysed_range(renderer, oracle_mod
                                                   ("3000", 120, 68, 147, 0), ("book", 131, 57, 211, 0), ("book", 150, 80, 69, 0),
                                                   ("3000", 97, 61, 100, 0)])
 def test_large_work_blocks_bit_exact(oracle_mod, book1_flat, scene, w, h, spp, flags):
-    """Launches of >= 2^28 pixel-samples at >= 69 samples per pixel hand out work in blocks of 1 024 pixel-samples instead of
+    """Launches of >= 2 x 10^8 pixel-samples at >= 69 samples per pixel hand out work in blocks of 1 024 pixel-samples instead of
     256 (another instantiation of the kernel, whose ring of block sums is 2 blocks x 16 pixels instead of 4 x 8: rt_stats.kernel_variant bit 2).  RTIOW_LARGE_BLOCK_MIN_ITEMS=0 selects it for a
     launch small enough for the oracle: both grid variants, the 53-bit stream, ragged sizes (a last block that is not full,
     blocks that straddle rows), and a second pass with sample_begin -- against Oracle B, bit for bit."""
